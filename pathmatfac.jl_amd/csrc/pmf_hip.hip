@@ -1,0 +1,1370 @@
+// pmf_hip.hip -- libpmf_hip.so : MI355X (gfx950) implementation of PathMatFac's fit! loop behind the C ABI of
+// include/pmf_hip.h.  Written for CDNA4 only (wave64, v_mfma_f32_32x32x2_f32, 160 KiB LDS).
+#include <hip/hip_runtime.h>
+
+#include <chrono>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/pmf_hip.h"
+#include "pmf_fused.hip.inc"
+
+// ------------------------------------------------------------------------------------------------
+// error handling
+// ------------------------------------------------------------------------------------------------
+static thread_local std::string g_err;
+static int pmf_fail(const char *fmt, ...) {
+  char buf[1024];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  g_err = buf;
+  return -1;
+}
+#define HIPCHK(x)                                                                                    \
+  do {                                                                                               \
+    hipError_t e_ = (x);                                                                             \
+    if (e_ != hipSuccess) return pmf_fail("%s failed: %s (%s:%d)", #x, hipGetErrorString(e_), __FILE__, __LINE__); \
+  } while (0)
+#define PMFCHK(x)          \
+  do {                     \
+    int r_ = (x);          \
+    if (r_ < 0) return r_; \
+  } while (0)
+
+extern "C" const char *pmf_last_error(void) { return g_err.c_str(); }
+extern "C" int pmf_version(void) { return 1; }
+
+// ------------------------------------------------------------------------------------------------
+// context
+// ------------------------------------------------------------------------------------------------
+struct ParamBuf {  // one trainable parameter tensor with its gradient, optimizer state and quadratic regularizer
+  float *p = nullptr, *g = nullptr, *acc = nullptr, *mom = nullptr;
+  float *wq = nullptr, *cq = nullptr;  // dense quadratic weights / centres: 0.5*wq*(p-cq)^2 (nullptr = none)
+  int64_t n = 0;
+  float bp1 = 0.f, bp2 = 0.f;  // Adam running beta powers
+};
+
+struct pmf_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool own_stream = true;
+  int n_cu = 256;
+  int64_t M = 0, N = 0;
+  int K = 0, Kp = 0, KB = 0;
+  float *D = nullptr;  // M x D_Npad, pad columns NaN
+  bool own_D = false;
+  int64_t D_M = 0, D_Npad = 0;
+  int store = PMF_STORE_F32;
+  ParamBuf P[6];  // X, Y, logsigma, mu, logdelta, theta
+  // batch views
+  int n_bv = 0;
+  std::vector<ViewDesc> views;
+  std::vector<int64_t> val_off;  // per view offset into the flat logdelta/theta arrays
+  std::vector<int64_t> bvb_off;  // per view offset into the flat per-(view,batch) arrays
+  int32_t *bor = nullptr;
+  float2 *btab = nullptr;
+  int32_t *d_val_view = nullptr;  // per flat value element: view id
+  // noise model / prepared column parameters
+  int32_t *colmeta = nullptr;  // kind | (view+1)<<2
+  float *colw = nullptr;
+  float4 *colp = nullptr;
+  bool mixed = false;
+  bool prepared = false;
+  // ARD-type regularizer on Y
+  float *ard_alpha = nullptr, *ard_beta = nullptr;
+  float ard_scale = 0.f;
+  bool has_ard = false;
+  // optimizer
+  int opt_kind = PMF_OPT_ADAGRAD;
+  float lr = 1.f, eps = 1e-8f, b1 = 0.9f, b2 = 0.999f;
+  bool state_init = false;
+  // loss plumbing
+  double *loss_partial = nullptr;
+  int64_t loss_cap = 0;
+  int64_t n_macro = 0;
+  double *reg_partial = nullptr;  // [4][REG_SLOTS]
+  double *d_loss = nullptr;       // device [8]
+  double *h_loss = nullptr;       // pinned host [8]
+  // fused-kernel timing
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
+  size_t ev_used = 0;
+  double kernel_ms_sum = 0.0;
+  int64_t kernel_launches = 0;
+  int reg_counts[4] = {0, 0, 0, 0};  // used slots of the regularizer partial slabs (0 X, 1 Y, 2 column layers)
+  // scratch
+  void *scratch = nullptr;
+  size_t scratch_bytes = 0;
+};
+
+#define REG_SLOTS 1024
+
+static int ctx_bind(pmf_ctx *c) {
+  if (!c) return pmf_fail("null context");
+  HIPCHK(hipSetDevice(c->device));
+  return 0;
+}
+
+template <typename T>
+static int dev_alloc(T **p, size_t n, bool zero = true) {
+  if (*p) {
+    HIPCHK(hipFree(*p));
+    *p = nullptr;
+  }
+  if (n == 0) n = 1;
+  HIPCHK(hipMalloc((void **)p, n * sizeof(T)));
+  if (zero) HIPCHK(hipMemset(*p, 0, n * sizeof(T)));
+  return 0;
+}
+template <typename T>
+static void dev_free(T **p) {
+  if (*p) (void)hipFree(*p);
+  *p = nullptr;
+}
+
+static int param_alloc(ParamBuf &b, int64_t n) {
+  b.n = n;
+  PMFCHK(dev_alloc(&b.p, n));
+  PMFCHK(dev_alloc(&b.g, n));
+  PMFCHK(dev_alloc(&b.acc, n));
+  PMFCHK(dev_alloc(&b.mom, n));
+  dev_free(&b.wq);
+  dev_free(&b.cq);
+  return 0;
+}
+static void param_free(ParamBuf &b) {
+  dev_free(&b.p); dev_free(&b.g); dev_free(&b.acc); dev_free(&b.mom); dev_free(&b.wq); dev_free(&b.cq);
+  b.n = 0;
+}
+
+static int ensure_scratch(pmf_ctx *c, size_t bytes) {
+  if (c->scratch_bytes >= bytes) return 0;
+  if (c->scratch) HIPCHK(hipFree(c->scratch));
+  c->scratch = nullptr;
+  HIPCHK(hipMalloc(&c->scratch, bytes));
+  c->scratch_bytes = bytes;
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// small kernels
+// ------------------------------------------------------------------------------------------------
+__global__ void k_fill(float *p, int64_t n, float v) {
+  for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) p[e] = v;
+}
+
+// colp[j] = {exp(logsigma_j), mu_j, w_j, meta_j}; btab[e] = {exp(logdelta_e), theta_e}
+__global__ void k_prepare(const float *logsigma, const float *mu, const float *colw, const int32_t *colmeta,
+                          float4 *colp, int64_t N, const float *logdelta, const float *theta, float2 *btab,
+                          int64_t nbt) {
+  const int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (e < N) colp[e] = make_float4(expf(logsigma[e]), mu[e], colw[e], __int_as_float(colmeta[e]));
+  if (e < nbt) btab[e] = make_float2(expf(logdelta[e]), theta[e]);
+}
+
+// dense quadratic weights from ranges: wq[k, i] += p * w[g, k] for i in range g   (GroupRegularizer / L2Regularizer)
+__global__ void k_expand_group(float *wq, int Kp, int K, int64_t n, const int64_t *s1, const int64_t *e1,
+                               const float *w, int n_groups, float p) {
+  const int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (e >= n * Kp) return;
+  const int k = (int)(e % Kp);
+  const int64_t i = e / Kp;
+  if (k >= K) return;
+  float add = 0.f;
+  for (int g = 0; g < n_groups; ++g)
+    if (i + 1 >= s1[g] && i + 1 <= e1[g]) add += w[(int64_t)g * K + k];
+  wq[e] += p * add;
+}
+// same for a 1-D parameter (ColParamReg): per range weight and centre
+__global__ void k_expand_colparam(float *wq, float *cq, int64_t n, const int64_t *s1, const int64_t *e1,
+                                  const float *w, const float *c, int n_ranges) {
+  const int64_t j = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (j >= n) return;
+  float ww = 0.f, cc = 0.f;
+  for (int r = 0; r < n_ranges; ++r)
+    if (j + 1 >= s1[r] && j + 1 <= e1[r]) { ww = w[r]; cc = c[r]; }
+  wq[j] = ww;
+  cq[j] = cc;
+}
+// BatchArrayReg: per (view, batch) weight and centre broadcast over the view's columns
+__global__ void k_expand_batchreg(float *wq, float *cq, int64_t n, const int32_t *val_view, const int64_t *val_off,
+                                  const int32_t *nbs, const int64_t *bvb_off, const float *w, const float *c) {
+  const int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (e >= n) return;
+  const int v = val_view[e];
+  const int b = (int)((e - val_off[v]) % nbs[v]);
+  wq[e] = w[bvb_off[v] + b];
+  cq[e] = c[bvb_off[v] + b];
+}
+// ARDRegularizer ranges -> dense alpha[N], beta[Kp x N]
+__global__ void k_expand_ard(float *alpha, float *beta, int Kp, int64_t N, const int64_t *s1, const int64_t *e1,
+                             const float *a, const float *b, int n_ranges) {
+  const int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (e >= N * Kp) return;
+  const int64_t j = e / Kp;
+  float aa = 0.f, bb = 1.f;
+  bool hit = false;
+  for (int r = 0; r < n_ranges; ++r)
+    if (j + 1 >= s1[r] && j + 1 <= e1[r]) { aa = a[r]; bb = b[r]; hit = true; }
+  // columns outside every range are not regularized: encode as alpha = -0.5 (factor (0.5+alpha) = 0), beta = 1
+  if (!hit) { aa = -0.5f; bb = 1.f; }
+  beta[e] = bb;
+  if (e % Kp == 0) alpha[j] = aa;
+}
+__global__ void k_pad_copy(float *dst, const float *src, int Kp, int K, int64_t n, float padval) {
+  const int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (e >= n * Kp) return;
+  const int k = (int)(e % Kp);
+  dst[e] = k < K ? src[(e / Kp) * K + k] : padval;
+}
+
+__device__ __forceinline__ double block_reduce_sum(double v, double *sh) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  const int w = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) sh[w] = v;
+  __syncthreads();
+  double s = 0.0;
+  if (threadIdx.x == 0)
+    for (int q = 0; q < (int)(blockDim.x >> 6); ++q) s += sh[q];
+  return s;  // valid on thread 0
+}
+
+struct StepArgs {
+  float *p, *g, *acc, *mom;
+  const float *wq, *cq;          // quadratic regularizer (may be null)
+  const float *ard_alpha, *ard_beta;  // ARD-type regularizer (Y only; may be null)
+  float ard_scale;
+  int64_t n;   // elements
+  int Kp, K;   // leading dimension and number of live rows (Kp == K == 1 for vectors)
+  int opt_kind;
+  float lr, eps, b1, b2, c1, c2;  // c1 = 1 - beta1^t, c2 = 1 - beta2^t
+  int do_step;   // 0: only evaluate the regularizer loss (parameter frozen for stepping)
+  int use_reg;
+  double *reg_partial;  // [REG_SLOTS]
+};
+
+// Regularizer gradient + optimizer step, one pass over a parameter tensor.
+//   quadratic : 0.5*wq*(p-cq)^2  (L2Regularizer regularizers.jl:21-33, GroupRegularizer :423-446,
+//               ColParamReg :482-487, BatchArrayReg :795-815)
+//   ARD       : (0.5+alpha_j) log(1 + (0.5/beta) p^2), grad (alpha_j+0.5) p / (b beta)
+//               (ARDRegularizer :546-585, FeatureSetARDReg featureset_ard.jl:135-150)
+//   AdaGrad   : acc += g^2 ; p -= eta g/(sqrt(acc)+eps)   (optimizers.jl:6-13 ; acc starts at eps)
+//   Adam      : Flux.Optimise.Adam
+__global__ __launch_bounds__(256) void k_reg_step(const StepArgs a) {
+  __shared__ double sh[4];
+  double lacc = 0.0;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < a.n; e += stride) {
+    const int k = (int)(e % a.Kp);
+    if (k >= a.K) continue;
+    float p = a.p[e];
+    float g = a.g[e];
+    if (a.use_reg) {
+      if (a.wq) {
+        const float d = p - (a.cq ? a.cq[e] : 0.f);
+        const float gr = a.wq[e] * d;
+        lacc += 0.5 * (double)(gr * d);
+        g += gr;
+      }
+      if (a.ard_beta) {
+        const int64_t j = e / a.Kp;
+        const float be = a.ard_beta[e], al = a.ard_alpha[j];
+        const float b = 1.f + (0.5f / be) * (p * p);
+        lacc += (double)(a.ard_scale * (0.5f + al) * logf(b));
+        g += a.ard_scale * ((al + 0.5f) * p / (b * be));
+      }
+    }
+    if (a.do_step) {
+      if (a.opt_kind == PMF_OPT_ADAGRAD) {
+        const float acc = a.acc[e] + g * g;
+        a.acc[e] = acc;
+        p -= g * (a.lr / (sqrtf(acc) + a.eps));
+      } else {
+        const float m = a.b1 * a.mom[e] + (1.f - a.b1) * g;
+        const float v = a.b2 * a.acc[e] + (1.f - a.b2) * g * g;
+        a.mom[e] = m;
+        a.acc[e] = v;
+        p -= m / a.c1 / (sqrtf(v / a.c2) + a.eps) * a.lr;
+      }
+      a.p[e] = p;
+    }
+  }
+  const double s = block_reduce_sum(lacc, sh);
+  if (threadIdx.x == 0 && a.reg_partial) a.reg_partial[blockIdx.x] = s;
+}
+
+// fixed-order reduction of the loss partial slabs -> out[0..4]
+struct RegCounts { int c[4]; };
+__global__ __launch_bounds__(256) void k_loss_reduce(const double *data_partial, int64_t n_data, const double *reg_partial,
+                                                     const RegCounts reg_counts, double *out) {
+  __shared__ double sh[4];
+  for (int which = 0; which < 5; ++which) {
+    const double *src = which == 0 ? data_partial : reg_partial + (int64_t)(which - 1) * REG_SLOTS;
+    const int64_t n = which == 0 ? n_data : reg_counts.c[which - 1];
+    double v = 0.0;
+    for (int64_t e = threadIdx.x; e < n; e += blockDim.x) v += src[e];
+    const double s = block_reduce_sum(v, sh);
+    if (threadIdx.x == 0) out[which] = s;
+    __syncthreads();
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Layer-parameter gradient pass (update_col_layers stages S2/S7: init_theta! fit.jl:106-122, fit_joint :987-1000).
+// thread = column, sequential over a chunk of rows; per-(batch, column) sums live in LDS (no contention:
+// a thread only touches its own column).  Pull-backs as coded in the reference:
+//   theta_bar[b,j]    = sum_{i in b} g                      (batch_array.jl:141-143)
+//   mu_bar[j]         = sum_i g                             (layers.jl:83)
+//   logdelta_bar[b,j] = delta[b,j] * sum_{i in b} g * (a*sigma_j)   (batch_array.jl:203-204, 250)
+//   logsigma_bar[j]   = sigma_j * sum_i g * delta           (layers.jl:40-41; Q1: omits the input factor)
+// ------------------------------------------------------------------------------------------------
+struct LayerGradArgs {
+  const float *D, *X, *Y;
+  const float4 *colp;
+  const int32_t *bor;
+  const float2 *btab;
+  float *g_logsigma, *g_mu, *g_logdelta, *g_theta;  // any may be null
+  double *loss_partial;                             // may be null; one slot per block (flattened grid)
+  int64_t M, N;
+  int Kp, K, rows_per_block, max_nb;
+  ViewDesc views[PMF_MAXV];
+  int64_t val_off[PMF_MAXV];
+};
+
+__global__ __launch_bounds__(64) void k_layer_grad(const LayerGradArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem_lg[];
+  float *xs = reinterpret_cast<float *>(smem_lg);  // [Kp] current row of X (broadcast)
+  float *bacc = xs + a.Kp;                         // [2][max_nb][64] per-(batch,column) sums
+  __shared__ double sh[4];
+  const int tid = threadIdx.x;
+  const int64_t j = blockIdx.x * 64 + tid;
+  const bool col_ok = j < a.N;
+  const int64_t jc = col_ok ? j : a.N - 1;
+  const int64_t r0 = (int64_t)blockIdx.y * a.rows_per_block;
+  int64_t r1 = r0 + a.rows_per_block;
+  if (r1 > a.M) r1 = a.M;
+  const float4 cp = a.colp[jc];
+  const int meta = __float_as_int(cp.w);
+  const int kind = col_ok ? (meta & 3) : 3;
+  const int v = (meta >> 2) - 1;
+  ViewDesc vd = a.views[v >= 0 ? v : 0];
+  for (int e = tid; e < 2 * a.max_nb * 64; e += 64) bacc[e] = 0.f;
+  float smu = 0.f, sls = 0.f;
+  double lacc = 0.0;
+  const float *y = a.Y + jc * a.Kp;
+  for (int64_t i = r0; i < r1; ++i) {
+    __syncthreads();
+    for (int k = tid; k < a.Kp; k += 64) xs[k] = a.X[i * a.Kp + k];
+    __syncthreads();
+    float acc = 0.f;
+    for (int k = 0; k < a.K; ++k) acc = fmaf(xs[k], y[k], acc);
+    float dl = 1.f, th = 0.f;
+    int b = -1;
+    if (v >= 0) {
+      b = a.bor[(int64_t)v * a.M + i];
+      if (b >= 0) {
+        const float2 dt = a.btab[vd.tab_off + (jc - vd.c0) * vd.nb + b];
+        dl = dt.x;
+        th = dt.y;
+      }
+    }
+    const float yv = a.D[jc * a.M + i];
+    const float z1 = acc * cp.x;
+    const float z = fmaf(z1, dl, cp.y + th);
+    float l, g;
+    if (kind == PMF_NOISE_NORMAL) {
+      const float d = z - yv;
+      g = cp.z * d;
+      l = 0.5f * g * d;
+    } else if (kind == PMF_NOISE_BERNOULLI) {
+      const float e = __expf(-fabsf(z));
+      const float sp = fmaxf(z, 0.f) + __logf(1.f + e);
+      const float r = __frcp_rn(1.f + e);
+      const float sg = z >= 0.f ? r : e * r;
+      l = cp.z * (sp - yv * z);
+      g = cp.z * (sg - yv);
+    } else {
+      const float e = __expf(z);
+      l = cp.z * (e - yv * z);
+      g = cp.z * (e - yv);
+    }
+    const bool ok = (kind != 3) && (fabsf(yv) <= 3.402823466e38f);
+    if (!ok) { l = 0.f; g = 0.f; }
+    lacc += (double)l;
+    smu += g;
+    sls += g * dl;
+    if (b >= 0) {
+      bacc[b * 64 + tid] += g;
+      bacc[(a.max_nb + b) * 64 + tid] += g * z1;
+    }
+  }
+  if (col_ok) {
+    if (a.g_mu) atomicAdd(a.g_mu + j, smu);
+    if (a.g_logsigma) atomicAdd(a.g_logsigma + j, sls * cp.x);
+    if (v >= 0) {
+      for (int b = 0; b < vd.nb; ++b) {
+        const int64_t e = a.val_off[v] + (j - vd.c0) * vd.nb + b;
+        if (a.g_theta) atomicAdd(a.g_theta + e, bacc[b * 64 + tid]);
+        if (a.g_logdelta) {
+          const float dlt = a.btab[vd.tab_off + (j - vd.c0) * vd.nb + b].x;
+          atomicAdd(a.g_logdelta + e, bacc[(a.max_nb + b) * 64 + tid] * dlt);
+        }
+      }
+    }
+  }
+  const double s = block_reduce_sum(lacc, sh);
+  if (tid == 0 && a.loss_partial) a.loss_partial[(int64_t)blockIdx.y * gridDim.x + blockIdx.x] = s;
+}
+
+// Z = layers(X'Y) materialised (MF.forward, simulate_params.jl:247); also used by pmf_synth_data.
+struct ForwardArgs {
+  const float *X, *Y;
+  const float4 *colp;
+  const int32_t *bor;
+  const float2 *btab;
+  float *Z;
+  int64_t M, N;
+  int Kp, K;
+  int synth;
+  uint64_t seed;
+  float noise, frac_nan;
+  ViewDesc views[PMF_MAXV];
+};
+__device__ __forceinline__ uint64_t splitmix64(uint64_t x) {
+  x += 0x9E3779B97F4A7C15ull;
+  x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+  x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+  return x ^ (x >> 31);
+}
+__global__ __launch_bounds__(256) void k_forward(const ForwardArgs a) {
+  // block: 256 consecutive rows of one column -> coalesced stores along i
+  const int64_t j = blockIdx.y;
+  const int64_t i = blockIdx.x * 256ll + threadIdx.x;
+  __shared__ float ys[128];
+  for (int k = threadIdx.x; k < a.Kp; k += 256) ys[k] = a.Y[j * a.Kp + k];
+  __syncthreads();
+  if (i >= a.M) return;
+  const float *x = a.X + i * a.Kp;
+  float acc = 0.f;
+  for (int k = 0; k < a.K; ++k) acc = fmaf(x[k], ys[k], acc);
+  const float4 cp = a.colp[j];
+  const int meta = __float_as_int(cp.w);
+  const int v = (meta >> 2) - 1;
+  float dl = 1.f, th = 0.f;
+  if (v >= 0) {
+    const ViewDesc vd = a.views[v];
+    const int b = a.bor[(int64_t)v * a.M + i];
+    if (b >= 0) {
+      const float2 dt = a.btab[vd.tab_off + (j - vd.c0) * vd.nb + b];
+      dl = dt.x;
+      th = dt.y;
+    }
+  }
+  float z = fmaf(acc * cp.x, dl, cp.y + th);
+  if (a.synth) {
+    const uint64_t ctr = (uint64_t)(j * a.M + i);
+    const uint64_t r1 = splitmix64(a.seed ^ (ctr * 2ull));
+    const uint64_t r2 = splitmix64(a.seed ^ (ctr * 2ull + 1ull));
+    const float u1 = ((r1 >> 40) + 1.0f) * (1.0f / 16777217.0f);
+    const float u2 = (r1 & 0xFFFFFFull) * (1.0f / 16777216.0f);
+    const float nrm = sqrtf(-2.f * logf(u1)) * cosf(6.28318530718f * u2);
+    const int kind = meta & 3;
+    if (kind == PMF_NOISE_NORMAL) z += a.noise * nrm;
+    else if (kind == PMF_NOISE_BERNOULLI) z = (z + a.noise * nrm) > 0.f ? 1.f : 0.f;
+    else z = floorf(__expf(fminf(z, 10.f)));
+    const float u3 = (r2 >> 40) * (1.0f / 16777216.0f);
+    if (u3 < a.frac_nan) z = __int_as_float(0x7fc00000);
+  }
+  a.Z[j * a.M + i] = z;
+}
+
+// ------------------------------------------------------------------------------------------------
+// host side helpers
+// ------------------------------------------------------------------------------------------------
+static inline int nblocks(int64_t n, int bs) { return (int)((n + bs - 1) / bs); }
+
+static int upload_padded(pmf_ctx *c, float *dst, const float *src, int64_t n, float padval) {
+  // src: host K x n ; dst: device Kp x n
+  if (c->K == c->Kp) {
+    HIPCHK(hipMemcpyAsync(dst, src, sizeof(float) * (size_t)(n * c->K), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return 0;
+  }
+  PMFCHK(ensure_scratch(c, sizeof(float) * (size_t)(n * c->K)));
+  HIPCHK(hipMemcpyAsync(c->scratch, src, sizeof(float) * (size_t)(n * c->K), hipMemcpyHostToDevice, c->stream));
+  k_pad_copy<<<nblocks(n * c->Kp, 256), 256, 0, c->stream>>>(dst, (const float *)c->scratch, c->Kp, c->K, n, padval);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return 0;
+}
+static int download_padded(pmf_ctx *c, float *dst_host, const float *src_dev, int64_t n) {
+  HIPCHK(hipMemcpy2DAsync(dst_host, sizeof(float) * c->K, src_dev, sizeof(float) * c->Kp, sizeof(float) * c->K,
+                          (size_t)n, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return 0;
+}
+template <typename T>
+static int upload_vec(pmf_ctx *c, T *dst, const T *src, size_t n) {
+  if (n == 0) return 0;
+  HIPCHK(hipMemcpyAsync(dst, src, sizeof(T) * n, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+static int set_K(pmf_ctx *c, int K) {
+  if (K <= 0 || K > 128) return pmf_fail("K=%d unsupported (1..128)", K);
+  if (c->M <= 0 || c->N <= 0) return pmf_fail("pmf_set_data must be called before pmf_set_factors");
+  if (K == c->K && c->P[0].n == (int64_t)c->Kp * c->M && c->P[1].n == (int64_t)c->Kp * c->N) return 0;
+  c->K = K;
+  c->KB = (K + 31) / 32;
+  c->Kp = 32 * c->KB;
+  PMFCHK(param_alloc(c->P[0], (int64_t)c->Kp * c->M));
+  PMFCHK(param_alloc(c->P[1], (int64_t)c->Kp * c->N));
+  dev_free(&c->ard_alpha);
+  dev_free(&c->ard_beta);
+  c->has_ard = false;
+  c->state_init = false;
+  return 0;
+}
+
+extern "C" int pmf_create(int device, pmf_ctx **out) {
+  if (!out) return pmf_fail("null out");
+  int ndev = 0;
+  HIPCHK(hipGetDeviceCount(&ndev));
+  if (device < 0 || device >= ndev) return pmf_fail("device %d out of range (%d visible)", device, ndev);
+  HIPCHK(hipSetDevice(device));
+  hipDeviceProp_t prop;
+  HIPCHK(hipGetDeviceProperties(&prop, device));
+  if (std::string(prop.gcnArchName).find("gfx950") == std::string::npos)
+    return pmf_fail("libpmf_hip is built for gfx950 (MI355X) only; device %d is %s", device, prop.gcnArchName);
+  pmf_ctx *c = new pmf_ctx();
+  c->device = device;
+  c->n_cu = prop.multiProcessorCount;
+  HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+  c->own_stream = true;
+  HIPCHK(hipMalloc((void **)&c->d_loss, sizeof(double) * 8));
+  HIPCHK(hipHostMalloc((void **)&c->h_loss, sizeof(double) * 8));
+  HIPCHK(hipMalloc((void **)&c->reg_partial, sizeof(double) * 4 * REG_SLOTS));
+  HIPCHK(hipMemset(c->reg_partial, 0, sizeof(double) * 4 * REG_SLOTS));
+  *out = c;
+  return 0;
+}
+
+extern "C" int pmf_destroy(pmf_ctx *c) {
+  if (!c) return 0;
+  (void)hipSetDevice(c->device);
+  (void)hipStreamSynchronize(c->stream);
+  for (auto &b : c->P) param_free(b);
+  if (c->own_D) dev_free(&c->D);
+  dev_free(&c->bor); dev_free(&c->btab); dev_free(&c->d_val_view);
+  dev_free(&c->colmeta); dev_free(&c->colw); dev_free(&c->colp);
+  dev_free(&c->ard_alpha); dev_free(&c->ard_beta);
+  dev_free(&c->loss_partial); dev_free(&c->reg_partial); dev_free(&c->d_loss);
+  if (c->h_loss) (void)hipHostFree(c->h_loss);
+  if (c->scratch) (void)hipFree(c->scratch);
+  for (auto &e : c->ev_pool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+  if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
+  delete c;
+  return 0;
+}
+
+extern "C" int pmf_set_stream(pmf_ctx *c, void *s) {
+  PMFCHK(ctx_bind(c));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  if (s == nullptr) {
+    if (!c->own_stream) {
+      HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+      c->own_stream = true;
+    }
+    return 0;
+  }
+  if (c->own_stream && c->stream) HIPCHK(hipStreamDestroy(c->stream));
+  c->stream = (hipStream_t)s;
+  c->own_stream = false;
+  return 0;
+}
+extern "C" int pmf_synchronize(pmf_ctx *c) {
+  PMFCHK(ctx_bind(c));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+static int data_shape_changed(pmf_ctx *c, int64_t M, int64_t N) {
+  if (M <= 0 || N <= 0) return pmf_fail("empty data matrix (%lld x %lld)", (long long)M, (long long)N);
+  if (M == c->M && N == c->N) return 0;
+  c->M = M;
+  c->N = N;
+  for (auto &b : c->P) param_free(b);
+  c->K = c->Kp = c->KB = 0;
+  PMFCHK(param_alloc(c->P[2], N));
+  PMFCHK(param_alloc(c->P[3], N));
+  c->n_bv = 0;
+  c->views.clear();
+  c->val_off.clear();
+  c->bvb_off.clear();
+  dev_free(&c->bor); dev_free(&c->btab); dev_free(&c->d_val_view);
+  PMFCHK(dev_alloc(&c->colmeta, (size_t)N));
+  PMFCHK(dev_alloc(&c->colw, (size_t)N));
+  PMFCHK(dev_alloc(&c->colp, (size_t)N));
+  k_fill<<<nblocks(N, 256), 256, 0, c->stream>>>(c->colw, N, 1.f);
+  HIPCHK(hipGetLastError());
+  c->mixed = false;
+  c->prepared = false;
+  c->state_init = false;
+  return 0;
+}
+
+// The device copy of D is M x Npad with Npad = roundup(N, PMF_BN); the pad columns hold NaN (= missing), so
+// the fused kernel needs no column bounds checks.
+static int alloc_padded_D(pmf_ctx *c, int64_t M, int64_t N) {
+  const int64_t Npad = (N + PMF_BN - 1) / PMF_BN * PMF_BN;
+  if (44.0 * (double)M * 4.0 >= 4294967296.0) return pmf_fail("M=%lld rows per device exceeds the 32-bit tile offset range", (long long)M);
+  if (!(c->own_D && c->D && c->D_M == M && c->D_Npad == Npad)) {
+    if (c->own_D) dev_free(&c->D);
+    c->D = nullptr;
+    HIPCHK(hipMalloc((void **)&c->D, sizeof(float) * (size_t)(M * Npad)));
+    c->own_D = true;
+    c->D_M = M;
+    c->D_Npad = Npad;
+  }
+  if (Npad > N) {
+    k_fill<<<nblocks(M * (Npad - N), 256), 256, 0, c->stream>>>(c->D + M * N, M * (Npad - N), __builtin_nanf(""));
+    HIPCHK(hipGetLastError());
+  }
+  return 0;
+}
+
+extern "C" int pmf_set_data(pmf_ctx *c, const float *D, int64_t M, int64_t N, int store) {
+  PMFCHK(ctx_bind(c));
+  if (!D) return pmf_fail("null data pointer");
+  if (store != PMF_STORE_F32) return pmf_fail("only PMF_STORE_F32 is implemented");
+  PMFCHK(data_shape_changed(c, M, N));
+  PMFCHK(alloc_padded_D(c, M, N));
+  HIPCHK(hipMemcpyAsync(c->D, D, sizeof(float) * (size_t)(M * N), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  c->store = store;
+  return 0;
+}
+extern "C" int pmf_set_data_device(pmf_ctx *c, const void *D, int64_t M, int64_t N, int store) {
+  PMFCHK(ctx_bind(c));
+  if (store != PMF_STORE_F32) return pmf_fail("only PMF_STORE_F32 is implemented");
+  PMFCHK(data_shape_changed(c, M, N));
+  if (D != nullptr && N % PMF_BN == 0 && 44.0 * (double)M * 4.0 < 4294967296.0) {
+    // adopt the caller's matrix in place (no pad columns needed)
+    if (c->own_D) dev_free(&c->D);
+    c->own_D = false;
+    c->D = (float *)D;
+    c->D_M = M;
+    c->D_Npad = N;
+  } else {
+    // library-owned padded matrix: device-to-device copy, or left uninitialised for pmf_synth_data (D == NULL)
+    PMFCHK(alloc_padded_D(c, M, N));
+    if (D) HIPCHK(hipMemcpyAsync(c->D, D, sizeof(float) * (size_t)(M * N), hipMemcpyDeviceToDevice, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+  }
+  c->store = store;
+  return 0;
+}
+
+extern "C" int pmf_set_factors(pmf_ctx *c, const float *X, const float *Y, int K) {
+  PMFCHK(ctx_bind(c));
+  if (!X || !Y) return pmf_fail("null factor pointer");
+  PMFCHK(set_K(c, K));
+  PMFCHK(upload_padded(c, c->P[0].p, X, c->M, 0.f));
+  PMFCHK(upload_padded(c, c->P[1].p, Y, c->N, 0.f));
+  return 0;
+}
+extern "C" int pmf_set_X(pmf_ctx *c, const float *X, int K) {
+  PMFCHK(ctx_bind(c));
+  if (K != c->K) return pmf_fail("pmf_set_X: K=%d differs from the current K=%d (use pmf_set_factors)", K, c->K);
+  return upload_padded(c, c->P[0].p, X, c->M, 0.f);
+}
+extern "C" int pmf_set_Y(pmf_ctx *c, const float *Y, int K) {
+  PMFCHK(ctx_bind(c));
+  if (K != c->K) return pmf_fail("pmf_set_Y: K=%d differs from the current K=%d (use pmf_set_factors)", K, c->K);
+  return upload_padded(c, c->P[1].p, Y, c->N, 0.f);
+}
+extern "C" int pmf_get_factors(pmf_ctx *c, float *X, float *Y) {
+  PMFCHK(ctx_bind(c));
+  if (c->K == 0) return pmf_fail("factors not set");
+  if (X) PMFCHK(download_padded(c, X, c->P[0].p, c->M));
+  if (Y) PMFCHK(download_padded(c, Y, c->P[1].p, c->N));
+  return 0;
+}
+
+extern "C" int pmf_set_col_params(pmf_ctx *c, const float *logsigma, const float *mu) {
+  PMFCHK(ctx_bind(c));
+  if (c->N == 0) return pmf_fail("data not set");
+  if (logsigma) PMFCHK(upload_vec(c, c->P[2].p, logsigma, (size_t)c->N));
+  if (mu) PMFCHK(upload_vec(c, c->P[3].p, mu, (size_t)c->N));
+  c->prepared = false;
+  return 0;
+}
+extern "C" int pmf_get_col_params(pmf_ctx *c, float *logsigma, float *mu) {
+  PMFCHK(ctx_bind(c));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  if (logsigma) HIPCHK(hipMemcpy(logsigma, c->P[2].p, sizeof(float) * (size_t)c->N, hipMemcpyDeviceToHost));
+  if (mu) HIPCHK(hipMemcpy(mu, c->P[3].p, sizeof(float) * (size_t)c->N, hipMemcpyDeviceToHost));
+  return 0;
+}
+
+// ---- batch views -------------------------------------------------------------------------------
+static int rebuild_colmeta_views(pmf_ctx *c) {
+  // refresh the view id bits of colmeta from the current views (kind bits are kept)
+  std::vector<int32_t> meta((size_t)c->N);
+  HIPCHK(hipStreamSynchronize(c->stream));
+  HIPCHK(hipMemcpy(meta.data(), c->colmeta, sizeof(int32_t) * (size_t)c->N, hipMemcpyDeviceToHost));
+  for (auto &m : meta) m &= 3;
+  for (int v = 0; v < c->n_bv; ++v) {
+    const ViewDesc &vd = c->views[v];
+    if (vd.nb <= 0) continue;
+    for (int64_t j = vd.c0; j < vd.c1; ++j) meta[(size_t)j] |= (v + 1) << 2;
+  }
+  HIPCHK(hipMemcpy(c->colmeta, meta.data(), sizeof(int32_t) * (size_t)c->N, hipMemcpyHostToDevice));
+  c->prepared = false;
+  return 0;
+}
+
+extern "C" int pmf_set_n_batch_views(pmf_ctx *c, int n) {
+  PMFCHK(ctx_bind(c));
+  if (n < 0 || n > PMF_MAXV) return pmf_fail("n_batch_views=%d out of range (0..%d)", n, PMF_MAXV);
+  if (c->N == 0) return pmf_fail("data not set");
+  c->n_bv = n;
+  c->views.assign((size_t)n, ViewDesc{0, 0, 0, 0, 0});
+  c->val_off.assign((size_t)n + 1, 0);
+  c->bvb_off.assign((size_t)n + 1, 0);
+  param_free(c->P[4]);
+  param_free(c->P[5]);
+  dev_free(&c->btab);
+  dev_free(&c->d_val_view);
+  PMFCHK(dev_alloc(&c->bor, (size_t)std::max<int64_t>(1, (int64_t)n * c->M)));
+  if (n > 0) HIPCHK(hipMemset(c->bor, 0xFF, sizeof(int32_t) * (size_t)((int64_t)n * c->M)));
+  PMFCHK(rebuild_colmeta_views(c));
+  c->state_init = false;
+  return 0;
+}
+
+extern "C" int pmf_set_batch_view(pmf_ctx *c, int v, int64_t s1, int64_t e1, int nb, const int32_t *batch_of_row,
+                                  const float *logdelta, const float *theta) {
+  PMFCHK(ctx_bind(c));
+  if (v < 0 || v >= c->n_bv) return pmf_fail("batch view %d out of range (n=%d)", v, c->n_bv);
+  if (s1 < 1 || e1 > c->N || s1 > e1) return pmf_fail("batch view %d: bad column range %lld:%lld", v, (long long)s1, (long long)e1);
+  if (nb <= 0) return pmf_fail("batch view %d: nb=%d", v, nb);
+  if (v > 0 && c->views[v - 1].nb == 0) return pmf_fail("batch views must be set in order (view %d is unset)", v - 1);
+  if (v > 0 && s1 - 1 < c->views[v - 1].c1) return pmf_fail("batch view %d overlaps / precedes view %d", v, v - 1);
+  const int64_t Nv = e1 - s1 + 1;
+  for (int64_t i = 0; i < c->M; ++i)
+    if (batch_of_row[i] < -1 || batch_of_row[i] >= nb) return pmf_fail("batch view %d: batch_of_row[%lld]=%d out of range", v, (long long)i, batch_of_row[i]);
+  const bool same_shape = c->views[v].nb == nb && c->views[v].c0 == s1 - 1 && c->views[v].c1 == e1 && c->P[4].n > 0 &&
+                          c->val_off[v + 1] - c->val_off[v] == Nv * nb;
+  c->views[v].c0 = s1 - 1;
+  c->views[v].c1 = e1;
+  c->views[v].nb = nb;
+  HIPCHK(hipMemcpy(c->bor + (int64_t)v * c->M, batch_of_row, sizeof(int32_t) * (size_t)c->M, hipMemcpyHostToDevice));
+  if (!same_shape) {
+    // (re)compute offsets for views >= v and reallocate the flat arrays once the last view is known
+    for (int u = v; u < c->n_bv; ++u) {
+      const int64_t sz = c->views[u].nb > 0 ? (c->views[u].c1 - c->views[u].c0) * c->views[u].nb : 0;
+      c->val_off[u + 1] = c->val_off[u] + sz;
+      c->bvb_off[u + 1] = c->bvb_off[u] + c->views[u].nb;
+      c->views[u].tab_off = c->val_off[u];
+    }
+    const int64_t tot = c->val_off[c->n_bv];
+    // keep already uploaded values of earlier views
+    std::vector<float> old_ld, old_th;
+    const int64_t keep = c->val_off[v];
+    if (c->P[4].n >= keep && keep > 0) {
+      old_ld.resize((size_t)keep);
+      old_th.resize((size_t)keep);
+      HIPCHK(hipMemcpy(old_ld.data(), c->P[4].p, sizeof(float) * (size_t)keep, hipMemcpyDeviceToHost));
+      HIPCHK(hipMemcpy(old_th.data(), c->P[5].p, sizeof(float) * (size_t)keep, hipMemcpyDeviceToHost));
+    }
+    PMFCHK(param_alloc(c->P[4], tot));
+    PMFCHK(param_alloc(c->P[5], tot));
+    if (!old_ld.empty()) {
+      HIPCHK(hipMemcpy(c->P[4].p, old_ld.data(), sizeof(float) * old_ld.size(), hipMemcpyHostToDevice));
+      HIPCHK(hipMemcpy(c->P[5].p, old_th.data(), sizeof(float) * old_th.size(), hipMemcpyHostToDevice));
+    }
+    PMFCHK(dev_alloc(&c->btab, (size_t)std::max<int64_t>(1, tot)));
+    std::vector<int32_t> vv((size_t)std::max<int64_t>(1, tot), 0);
+    for (int u = 0; u < c->n_bv; ++u)
+      for (int64_t e = c->val_off[u]; e < c->val_off[u + 1]; ++e) vv[(size_t)e] = u;
+    PMFCHK(dev_alloc(&c->d_val_view, vv.size()));
+    HIPCHK(hipMemcpy(c->d_val_view, vv.data(), sizeof(int32_t) * vv.size(), hipMemcpyHostToDevice));
+    c->state_init = false;
+  }
+  const int64_t off = c->val_off[v];
+  if (logdelta) HIPCHK(hipMemcpy(c->P[4].p + off, logdelta, sizeof(float) * (size_t)(Nv * nb), hipMemcpyHostToDevice));
+  if (theta) HIPCHK(hipMemcpy(c->P[5].p + off, theta, sizeof(float) * (size_t)(Nv * nb), hipMemcpyHostToDevice));
+  PMFCHK(rebuild_colmeta_views(c));
+  return 0;
+}
+
+extern "C" int pmf_get_batch_view(pmf_ctx *c, int v, float *logdelta, float *theta) {
+  PMFCHK(ctx_bind(c));
+  if (v < 0 || v >= c->n_bv) return pmf_fail("batch view %d out of range (n=%d)", v, c->n_bv);
+  HIPCHK(hipStreamSynchronize(c->stream));
+  const int64_t off = c->val_off[v], n = c->val_off[v + 1] - off;
+  if (logdelta) HIPCHK(hipMemcpy(logdelta, c->P[4].p + off, sizeof(float) * (size_t)n, hipMemcpyDeviceToHost));
+  if (theta) HIPCHK(hipMemcpy(theta, c->P[5].p + off, sizeof(float) * (size_t)n, hipMemcpyDeviceToHost));
+  return 0;
+}
+
+// ---- noise model -------------------------------------------------------------------------------
+extern "C" int pmf_set_noise(pmf_ctx *c, int n_ranges, const int64_t *s1, const int64_t *e1, const int32_t *kinds,
+                             const float *weights) {
+  PMFCHK(ctx_bind(c));
+  if (c->N == 0) return pmf_fail("data not set");
+  std::vector<int32_t> meta((size_t)c->N, 3);
+  bool mixed = false;
+  for (int r = 0; r < n_ranges; ++r) {
+    if (s1[r] < 1 || e1[r] > c->N || s1[r] > e1[r]) return pmf_fail("noise range %d: bad columns %lld:%lld", r, (long long)s1[r], (long long)e1[r]);
+    if (kinds[r] < 0 || kinds[r] > 2) return pmf_fail("noise range %d: unsupported kind %d (normal=0, bernoulli=1, poisson=2)", r, kinds[r]);
+    if (kinds[r] != PMF_NOISE_NORMAL) mixed = true;
+    for (int64_t j = s1[r] - 1; j < e1[r]; ++j) meta[(size_t)j] = kinds[r];
+  }
+  for (int64_t j = 0; j < c->N; ++j)
+    if (meta[(size_t)j] == 3) return pmf_fail("noise model does not cover column %lld", (long long)(j + 1));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  HIPCHK(hipMemcpy(c->colmeta, meta.data(), sizeof(int32_t) * (size_t)c->N, hipMemcpyHostToDevice));
+  if (weights) HIPCHK(hipMemcpy(c->colw, weights, sizeof(float) * (size_t)c->N, hipMemcpyHostToDevice));
+  c->mixed = mixed;
+  PMFCHK(rebuild_colmeta_views(c));
+  return 0;
+}
+
+// ---- regularizers ------------------------------------------------------------------------------
+static int add_quad_ranges(pmf_ctx *c, int which, int n_groups, const int64_t *s1, const int64_t *e1, const float *w, float p) {
+  if (c->K == 0) return pmf_fail("factors must be set before their regularizers");
+  ParamBuf &b = c->P[which];
+  const int64_t n = which == 0 ? c->M : c->N;
+  for (int g = 0; g < n_groups; ++g)
+    if (s1[g] < 1 || e1[g] > n || s1[g] > e1[g]) return pmf_fail("regularizer range %d: bad %lld:%lld (n=%lld)", g, (long long)s1[g], (long long)e1[g], (long long)n);
+  if (!b.wq) PMFCHK(dev_alloc(&b.wq, (size_t)b.n));
+  int64_t *ds = nullptr, *de = nullptr;
+  float *dw = nullptr;
+  PMFCHK(dev_alloc(&ds, (size_t)n_groups, false));
+  PMFCHK(dev_alloc(&de, (size_t)n_groups, false));
+  PMFCHK(dev_alloc(&dw, (size_t)n_groups * c->K, false));
+  HIPCHK(hipMemcpy(ds, s1, sizeof(int64_t) * n_groups, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(de, e1, sizeof(int64_t) * n_groups, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(dw, w, sizeof(float) * (size_t)n_groups * c->K, hipMemcpyHostToDevice));
+  k_expand_group<<<nblocks(b.n, 256), 256, 0, c->stream>>>(b.wq, c->Kp, c->K, n, ds, de, dw, n_groups, p);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(c->stream));
+  dev_free(&ds); dev_free(&de); dev_free(&dw);
+  return 0;
+}
+static int add_quad_l2(pmf_ctx *c, int which, const float *w, float p) {
+  const int64_t s1 = 1, e1 = which == 0 ? c->M : c->N;
+  return add_quad_ranges(c, which, 1, &s1, &e1, w, p);
+}
+extern "C" int pmf_clear_xreg(pmf_ctx *c) {
+  PMFCHK(ctx_bind(c));
+  dev_free(&c->P[0].wq);
+  return 0;
+}
+extern "C" int pmf_add_xreg_l2(pmf_ctx *c, const float *w, float p) {
+  PMFCHK(ctx_bind(c));
+  return add_quad_l2(c, 0, w, p);
+}
+extern "C" int pmf_add_xreg_group(pmf_ctx *c, int n, const int64_t *s1, const int64_t *e1, const float *w, float p) {
+  PMFCHK(ctx_bind(c));
+  return add_quad_ranges(c, 0, n, s1, e1, w, p);
+}
+extern "C" int pmf_clear_yreg(pmf_ctx *c) {
+  PMFCHK(ctx_bind(c));
+  dev_free(&c->P[1].wq);
+  c->has_ard = false;
+  return 0;
+}
+extern "C" int pmf_add_yreg_l2(pmf_ctx *c, const float *w, float p) {
+  PMFCHK(ctx_bind(c));
+  return add_quad_l2(c, 1, w, p);
+}
+extern "C" int pmf_add_yreg_group(pmf_ctx *c, int n, const int64_t *s1, const int64_t *e1, const float *w, float p) {
+  PMFCHK(ctx_bind(c));
+  return add_quad_ranges(c, 1, n, s1, e1, w, p);
+}
+extern "C" int pmf_add_yreg_ard(pmf_ctx *c, int n_ranges, const int64_t *s1, const int64_t *e1, const float *alpha,
+                                const float *beta, float p) {
+  PMFCHK(ctx_bind(c));
+  if (c->K == 0) return pmf_fail("factors must be set before their regularizers");
+  if (c->has_ard) return pmf_fail("only one ARD-type term (ARD or FeatureSetARD) is supported on Y");
+  for (int r = 0; r < n_ranges; ++r)
+    if (s1[r] < 1 || e1[r] > c->N || s1[r] > e1[r]) return pmf_fail("ARD range %d: bad %lld:%lld", r, (long long)s1[r], (long long)e1[r]);
+  if (!c->ard_alpha) PMFCHK(dev_alloc(&c->ard_alpha, (size_t)c->N));
+  if (!c->ard_beta) PMFCHK(dev_alloc(&c->ard_beta, (size_t)c->P[1].n));
+  int64_t *ds = nullptr, *de = nullptr;
+  float *da = nullptr, *db = nullptr;
+  PMFCHK(dev_alloc(&ds, (size_t)n_ranges, false));
+  PMFCHK(dev_alloc(&de, (size_t)n_ranges, false));
+  PMFCHK(dev_alloc(&da, (size_t)n_ranges, false));
+  PMFCHK(dev_alloc(&db, (size_t)n_ranges, false));
+  HIPCHK(hipMemcpy(ds, s1, sizeof(int64_t) * n_ranges, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(de, e1, sizeof(int64_t) * n_ranges, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(da, alpha, sizeof(float) * n_ranges, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(db, beta, sizeof(float) * n_ranges, hipMemcpyHostToDevice));
+  k_expand_ard<<<nblocks(c->P[1].n, 256), 256, 0, c->stream>>>(c->ard_alpha, c->ard_beta, c->Kp, c->N, ds, de, da, db, n_ranges);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(c->stream));
+  dev_free(&ds); dev_free(&de); dev_free(&da); dev_free(&db);
+  c->ard_scale = p;
+  c->has_ard = true;
+  return 0;
+}
+extern "C" int pmf_add_yreg_fsard(pmf_ctx *c, const float *alpha, const float *beta, float p) {
+  PMFCHK(ctx_bind(c));
+  if (c->K == 0) return pmf_fail("factors must be set before their regularizers");
+  if (c->has_ard) return pmf_fail("only one ARD-type term (ARD or FeatureSetARD) is supported on Y");
+  if (!c->ard_alpha) PMFCHK(dev_alloc(&c->ard_alpha, (size_t)c->N));
+  if (!c->ard_beta) PMFCHK(dev_alloc(&c->ard_beta, (size_t)c->P[1].n));
+  PMFCHK(upload_vec(c, c->ard_alpha, alpha, (size_t)c->N));
+  PMFCHK(upload_padded(c, c->ard_beta, beta, c->N, 1.f));
+  c->ard_scale = p;
+  c->has_ard = true;
+  return 0;
+}
+
+extern "C" int pmf_set_layer_regs(pmf_ctx *c, int n_ranges, const int64_t *s1, const int64_t *e1,
+                                  const float *w_ls, const float *c_ls, const float *w_mu, const float *c_mu,
+                                  const float *w_ld, const float *c_ld, const float *w_th, const float *c_th) {
+  PMFCHK(ctx_bind(c));
+  if (c->N == 0) return pmf_fail("data not set");
+  for (int which = 2; which <= 5; ++which) { dev_free(&c->P[which].wq); dev_free(&c->P[which].cq); }
+  if (n_ranges > 0) {
+    int64_t *ds = nullptr, *de = nullptr;
+    float *dw = nullptr, *dc = nullptr;
+    PMFCHK(dev_alloc(&ds, (size_t)n_ranges, false));
+    PMFCHK(dev_alloc(&de, (size_t)n_ranges, false));
+    PMFCHK(dev_alloc(&dw, (size_t)n_ranges, false));
+    PMFCHK(dev_alloc(&dc, (size_t)n_ranges, false));
+    HIPCHK(hipMemcpy(ds, s1, sizeof(int64_t) * n_ranges, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(de, e1, sizeof(int64_t) * n_ranges, hipMemcpyHostToDevice));
+    for (int t = 0; t < 2; ++t) {
+      const float *w = t == 0 ? w_ls : w_mu, *cc = t == 0 ? c_ls : c_mu;
+      if (!w || !cc) continue;
+      ParamBuf &b = c->P[2 + t];
+      PMFCHK(dev_alloc(&b.wq, (size_t)c->N));
+      PMFCHK(dev_alloc(&b.cq, (size_t)c->N));
+      HIPCHK(hipMemcpy(dw, w, sizeof(float) * n_ranges, hipMemcpyHostToDevice));
+      HIPCHK(hipMemcpy(dc, cc, sizeof(float) * n_ranges, hipMemcpyHostToDevice));
+      k_expand_colparam<<<nblocks(c->N, 256), 256, 0, c->stream>>>(b.wq, b.cq, c->N, ds, de, dw, dc, n_ranges);
+      HIPCHK(hipGetLastError());
+      HIPCHK(hipStreamSynchronize(c->stream));
+    }
+    dev_free(&ds); dev_free(&de); dev_free(&dw); dev_free(&dc);
+  }
+  if (c->n_bv > 0 && c->P[4].n > 0) {
+    const int64_t nbt = c->bvb_off[c->n_bv];
+    std::vector<int32_t> nbs((size_t)c->n_bv);
+    for (int v = 0; v < c->n_bv; ++v) nbs[v] = c->views[v].nb;
+    int32_t *dnb = nullptr;
+    int64_t *dvo = nullptr, *dbo = nullptr;
+    float *dw = nullptr, *dc = nullptr;
+    PMFCHK(dev_alloc(&dnb, (size_t)c->n_bv, false));
+    PMFCHK(dev_alloc(&dvo, (size_t)c->n_bv + 1, false));
+    PMFCHK(dev_alloc(&dbo, (size_t)c->n_bv + 1, false));
+    PMFCHK(dev_alloc(&dw, (size_t)nbt, false));
+    PMFCHK(dev_alloc(&dc, (size_t)nbt, false));
+    HIPCHK(hipMemcpy(dnb, nbs.data(), sizeof(int32_t) * c->n_bv, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(dvo, c->val_off.data(), sizeof(int64_t) * (c->n_bv + 1), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(dbo, c->bvb_off.data(), sizeof(int64_t) * (c->n_bv + 1), hipMemcpyHostToDevice));
+    for (int t = 0; t < 2; ++t) {
+      const float *w = t == 0 ? w_ld : w_th, *cc = t == 0 ? c_ld : c_th;
+      if (!w || !cc) continue;
+      ParamBuf &b = c->P[4 + t];
+      PMFCHK(dev_alloc(&b.wq, (size_t)b.n));
+      PMFCHK(dev_alloc(&b.cq, (size_t)b.n));
+      HIPCHK(hipMemcpy(dw, w, sizeof(float) * (size_t)nbt, hipMemcpyHostToDevice));
+      HIPCHK(hipMemcpy(dc, cc, sizeof(float) * (size_t)nbt, hipMemcpyHostToDevice));
+      k_expand_batchreg<<<nblocks(b.n, 256), 256, 0, c->stream>>>(b.wq, b.cq, b.n, c->d_val_view, dvo, dnb, dbo, dw, dc);
+      HIPCHK(hipGetLastError());
+      HIPCHK(hipStreamSynchronize(c->stream));
+    }
+    dev_free(&dnb); dev_free(&dvo); dev_free(&dbo); dev_free(&dw); dev_free(&dc);
+  }
+  return 0;
+}
+
+// ---- optimizer ---------------------------------------------------------------------------------
+extern "C" int pmf_set_optimizer(pmf_ctx *c, int kind, float lr, float eps, float b1, float b2) {
+  PMFCHK(ctx_bind(c));
+  if (kind != PMF_OPT_ADAGRAD && kind != PMF_OPT_ADAM) return pmf_fail("unknown optimizer kind %d", kind);
+  c->opt_kind = kind;
+  c->lr = lr;
+  c->eps = eps;
+  c->b1 = b1;
+  c->b2 = b2;
+  c->state_init = false;
+  return 0;
+}
+extern "C" int pmf_set_lr(pmf_ctx *c, float lr) {
+  PMFCHK(ctx_bind(c));
+  c->lr = lr;
+  return 0;
+}
+extern "C" int pmf_get_lr(pmf_ctx *c, float *lr) {
+  PMFCHK(ctx_bind(c));
+  *lr = c->lr;
+  return 0;
+}
+extern "C" int pmf_reset_optimizer_state(pmf_ctx *c) {
+  PMFCHK(ctx_bind(c));
+  c->state_init = false;
+  return 0;
+}
+static int init_opt_state(pmf_ctx *c) {
+  for (int w = 0; w < 6; ++w) {
+    ParamBuf &b = c->P[w];
+    if (b.n == 0) continue;
+    k_fill<<<nblocks(b.n, 256), 256, 0, c->stream>>>(b.acc, b.n, c->opt_kind == PMF_OPT_ADAGRAD ? c->eps : 0.f);
+    k_fill<<<nblocks(b.n, 256), 256, 0, c->stream>>>(b.mom, b.n, 0.f);
+    HIPCHK(hipGetLastError());
+    b.bp1 = c->b1;
+    b.bp2 = c->b2;
+  }
+  c->state_init = true;
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// epoch machinery
+// ------------------------------------------------------------------------------------------------
+static int prepare(pmf_ctx *c) {
+  const int64_t nbt = c->n_bv > 0 ? c->val_off[c->n_bv] : 0;
+  const int64_t n = std::max(c->N, nbt);
+  k_prepare<<<nblocks(n, 256), 256, 0, c->stream>>>(c->P[2].p, c->P[3].p, c->colw, c->colmeta, c->colp, c->N,
+                                                    c->P[4].p, c->P[5].p, c->btab, nbt);
+  HIPCHK(hipGetLastError());
+  c->prepared = true;
+  return 0;
+}
+
+template <int KB, int NW>
+static int launch_fused_t(pmf_ctx *c, const FusedArgs &a, int grid, bool batch, bool mixed) {
+  const size_t lds = pmf_fused_lds_bytes<KB, NW>();
+  void (*kern)(const FusedArgs) = nullptr;
+  if (batch) kern = mixed ? pmf_fused_kernel<KB, NW, true, true> : pmf_fused_kernel<KB, NW, true, false>;
+  else kern = mixed ? pmf_fused_kernel<KB, NW, false, true> : pmf_fused_kernel<KB, NW, false, false>;
+  static bool attr_set[4] = {false, false, false, false};
+  const int vi = (batch ? 2 : 0) + (mixed ? 1 : 0);
+  if (!attr_set[vi]) {
+    HIPCHK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_set[vi] = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * NW), lds, c->stream, a);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+static int harvest_events(pmf_ctx *c) {
+  for (size_t e = 0; e < c->ev_used; ++e) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, c->ev_pool[e].first, c->ev_pool[e].second) == hipSuccess) {
+      c->kernel_ms_sum += ms;
+      c->kernel_launches += 1;
+    }
+  }
+  c->ev_used = 0;
+  return 0;
+}
+
+static int launch_fused(pmf_ctx *c, bool want_gx, bool want_gy) {
+  const int NW = c->KB <= 2 ? 8 : 4;
+  const int BM = 32 * NW;
+  const int64_t n_rp = (c->M + BM - 1) / BM;
+  const int64_t n_ct = (c->N + PMF_BN - 1) / PMF_BN;  // column tiles
+  // column segments: enough macro tiles to balance the CUs, but at least 8 tiles (512 columns) per segment
+  int64_t n_cseg = 1;
+  const int64_t target = 16ll * c->n_cu;
+  if (n_rp < target) n_cseg = std::min<int64_t>((target + n_rp - 1) / n_rp, std::max<int64_t>(1, n_ct / 8));
+  const int64_t tiles_per_seg = (n_ct + n_cseg - 1) / n_cseg;
+  n_cseg = (n_ct + tiles_per_seg - 1) / tiles_per_seg;
+  const int64_t n_macro = n_rp * n_cseg;
+  if (n_macro > c->loss_cap) {
+    PMFCHK(dev_alloc(&c->loss_partial, (size_t)n_macro));
+    c->loss_cap = n_macro;
+  }
+  c->n_macro = n_macro;
+  FusedArgs a;
+  memset(&a, 0, sizeof(a));
+  a.D = c->D; a.X = c->P[0].p; a.Y = c->P[1].p; a.gX = c->P[0].g; a.gY = c->P[1].g;
+  a.colp = c->colp; a.bor = c->bor; a.btab = c->btab; a.loss_partial = c->loss_partial;
+  a.M = c->M; a.N = c->N; a.n_macro = n_macro; a.seg_cols = tiles_per_seg * PMF_BN; a.n_cseg = (int)n_cseg;
+  a.gx_atomic = n_cseg > 1;
+  a.want_gx = want_gx; a.want_gy = want_gy;
+  for (int v = 0; v < c->n_bv; ++v) a.views[v] = c->views[v];
+  const int grid = (int)std::min<int64_t>(n_macro, c->n_cu);
+  const bool batch = c->n_bv > 0;
+  // timing events
+  if (c->ev_used == c->ev_pool.size()) {
+    if (c->ev_pool.size() >= 4096) {
+      HIPCHK(hipStreamSynchronize(c->stream));
+      harvest_events(c);
+    } else {
+      hipEvent_t e0, e1;
+      HIPCHK(hipEventCreate(&e0));
+      HIPCHK(hipEventCreate(&e1));
+      c->ev_pool.emplace_back(e0, e1);
+    }
+  }
+  auto &ev = c->ev_pool[c->ev_used++];
+  HIPCHK(hipEventRecord(ev.first, c->stream));
+  int rc = 0;
+  switch (c->KB) {
+    case 1: rc = launch_fused_t<1, 8>(c, a, grid, batch, c->mixed); break;
+    case 2: rc = launch_fused_t<2, 8>(c, a, grid, batch, c->mixed); break;
+    case 3: rc = launch_fused_t<3, 4>(c, a, grid, batch, c->mixed); break;
+    case 4: rc = launch_fused_t<4, 4>(c, a, grid, batch, c->mixed); break;
+    default: return pmf_fail("unsupported KB=%d", c->KB);
+  }
+  PMFCHK(rc);
+  HIPCHK(hipEventRecord(ev.second, c->stream));
+  return 0;
+}
+
+static int launch_layer_grad(pmf_ctx *c, const pmf_fit_opts *o, bool with_loss) {
+  LayerGradArgs a;
+  memset(&a, 0, sizeof(a));
+  a.D = c->D; a.X = c->P[0].p; a.Y = c->P[1].p; a.colp = c->colp; a.bor = c->bor; a.btab = c->btab;
+  const int fl = o->frozen_layers;
+  a.g_logsigma = (fl & 1) ? nullptr : c->P[2].g;
+  a.g_logdelta = ((fl & 2) || c->n_bv == 0) ? nullptr : c->P[4].g;
+  a.g_mu = (fl & 4) ? nullptr : c->P[3].g;
+  a.g_theta = ((fl & 8) || c->n_bv == 0) ? nullptr : c->P[5].g;
+  a.M = c->M; a.N = c->N; a.Kp = c->Kp; a.K = c->K;
+  int max_nb = 1;
+  for (int v = 0; v < c->n_bv; ++v) {
+    a.views[v] = c->views[v];
+    a.val_off[v] = c->val_off[v];
+    max_nb = std::max(max_nb, c->views[v].nb);
+  }
+  a.max_nb = max_nb;
+  const int gx = nblocks(c->N, 64);
+  int64_t gy = std::max<int64_t>(1, std::min<int64_t>((4ll * c->n_cu + gx - 1) / gx, (c->M + 63) / 64));
+  a.rows_per_block = (int)((c->M + gy - 1) / gy);
+  gy = (c->M + a.rows_per_block - 1) / a.rows_per_block;
+  const int64_t nslots = (int64_t)gx * gy;
+  if (with_loss) {
+    if (nslots > c->loss_cap) {
+      PMFCHK(dev_alloc(&c->loss_partial, (size_t)nslots));
+      c->loss_cap = nslots;
+    }
+    c->n_macro = nslots;
+    a.loss_partial = c->loss_partial;
+  }
+  const size_t lds = sizeof(float) * (size_t)(c->Kp + 2 * max_nb * 64);
+  if (lds > 160 * 1024) return pmf_fail("too many row batches per view (%d) for the layer-gradient kernel", max_nb);
+  HIPCHK(hipFuncSetAttribute((const void *)k_layer_grad, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(k_layer_grad, dim3(gx, (unsigned)gy), dim3(64), lds, c->stream, a);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+static int check_ready(pmf_ctx *c) {
+  if (!c->D) return pmf_fail("data not set");
+  if (c->K == 0) return pmf_fail("factors not set");
+  for (int v = 0; v < c->n_bv; ++v)
+    if (c->views[v].nb == 0) return pmf_fail("batch view %d declared but not set", v);
+  return 0;
+}
+
+static int step_param(pmf_ctx *c, int which, bool do_step, bool use_reg, int reg_slot, int *reg_count) {
+  ParamBuf &b = c->P[which];
+  if (b.n == 0) return 0;
+  StepArgs s;
+  memset(&s, 0, sizeof(s));
+  s.p = b.p; s.g = b.g; s.acc = b.acc; s.mom = b.mom; s.wq = b.wq; s.cq = b.cq;
+  if (which == 1 && c->has_ard) { s.ard_alpha = c->ard_alpha; s.ard_beta = c->ard_beta; s.ard_scale = c->ard_scale; }
+  s.n = b.n;
+  s.Kp = which <= 1 ? c->Kp : 1;
+  s.K = which <= 1 ? c->K : 1;
+  s.opt_kind = c->opt_kind; s.lr = c->lr; s.eps = c->eps; s.b1 = c->b1; s.b2 = c->b2;
+  s.c1 = 1.f - b.bp1; s.c2 = 1.f - b.bp2;
+  s.do_step = do_step; s.use_reg = use_reg;
+  const int grid = (int)std::min<int64_t>(REG_SLOTS, nblocks(b.n, 256));
+  s.reg_partial = c->reg_partial + (int64_t)reg_slot * REG_SLOTS + *reg_count;
+  if (*reg_count + grid > REG_SLOTS) return pmf_fail("internal: regularizer partial slab overflow");
+  k_reg_step<<<grid, 256, 0, c->stream>>>(s);
+  HIPCHK(hipGetLastError());
+  *reg_count += grid;
+  if (do_step && c->opt_kind == PMF_OPT_ADAM) { b.bp1 *= c->b1; b.bp2 *= c->b2; }
+  return 0;
+}
+
+extern "C" int pmf_epoch_begin(pmf_ctx *c, const pmf_fit_opts *o) {
+  PMFCHK(ctx_bind(c));
+  PMFCHK(check_ready(c));
+  if (!o) return pmf_fail("null opts");
+  if (!c->state_init) PMFCHK(init_opt_state(c));
+  if (!c->prepared || o->update_col_layers) PMFCHK(prepare(c));
+  for (int q = 0; q < 4; ++q) c->reg_counts[q] = 0;
+  const bool fused = o->update_X || o->update_Y || !o->update_col_layers;
+  // gradients are accumulated with atomics: start every epoch from zero
+  if (o->update_X) HIPCHK(hipMemsetAsync(c->P[0].g, 0, sizeof(float) * (size_t)c->P[0].n, c->stream));
+  if (o->update_Y) HIPCHK(hipMemsetAsync(c->P[1].g, 0, sizeof(float) * (size_t)c->P[1].n, c->stream));
+  if (o->update_col_layers)
+    for (int w = 2; w < 6; ++w)
+      if (c->P[w].n) HIPCHK(hipMemsetAsync(c->P[w].g, 0, sizeof(float) * (size_t)c->P[w].n, c->stream));
+  if (fused) PMFCHK(launch_fused(c, o->update_X != 0, o->update_Y != 0));
+  if (o->update_col_layers) PMFCHK(launch_layer_grad(c, o, !fused));
+  return 0;
+}
+
+extern "C" int pmf_epoch_step_local(pmf_ctx *c, const pmf_fit_opts *o) {
+  PMFCHK(ctx_bind(c));
+  if (o->update_X) PMFCHK(step_param(c, 0, true, true, 0, &c->reg_counts[0]));
+  return 0;
+}
+
+extern "C" int pmf_epoch_step_shared(pmf_ctx *c, const pmf_fit_opts *o) {
+  PMFCHK(ctx_bind(c));
+  if (o->update_Y) PMFCHK(step_param(c, 1, true, true, 1, &c->reg_counts[1]));
+  if (o->update_col_layers) {
+    const int fl = o->frozen_layers, fr = o->frozen_regs;
+    // layer l <-> param: 1 logsigma(2), 2 logdelta(4), 3 mu(3), 4 theta(5)
+    const int pmap[4] = {2, 4, 3, 5};
+    for (int l = 0; l < 4; ++l) {
+      const bool frozen = (fl >> l) & 1;
+      const bool reg_on = !frozen && !((fr >> l) & 1);
+      if (frozen) continue;  // FrozenLayer: no step, regularizer evaluates to 0 (regularizers.jl:508-510, 887-889)
+      PMFCHK(step_param(c, pmap[l], true, reg_on, 2, &c->reg_counts[2]));
+    }
+    c->prepared = false;
+  }
+  return 0;
+}
+
+extern "C" int pmf_epoch_loss(pmf_ctx *c, double *local_loss, double *shared_terms) {
+  PMFCHK(ctx_bind(c));
+  RegCounts rc;
+  for (int q = 0; q < 4; ++q) rc.c[q] = c->reg_counts[q];
+  k_loss_reduce<<<1, 256, 0, c->stream>>>(c->loss_partial, c->n_macro, c->reg_partial, rc, c->d_loss);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpyAsync(c->h_loss, c->d_loss, sizeof(double) * 5, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  harvest_events(c);
+  const double shared = c->h_loss[2] + c->h_loss[3];
+  if (local_loss) *local_loss = c->h_loss[0] + c->h_loss[1] + shared;
+  if (shared_terms) *shared_terms = shared;
+  return 0;
+}
+
+extern "C" int pmf_fit(pmf_ctx *c, const pmf_fit_opts *o, pmf_fit_result *res) {
+  PMFCHK(ctx_bind(c));
+  PMFCHK(check_ready(c));
+  if (!o || !res) return pmf_fail("null opts/result");
+  const auto t0 = std::chrono::steady_clock::now();
+  int term = PMF_TERM_MAX_EPOCHS, tol_iters = 0, n = 0, last_epoch = o->epoch - 1;
+  double prev = 0.0, loss = 0.0;
+  const int tol_max = o->tol_max_iters > 0 ? o->tol_max_iters : 3;
+  for (int epoch = o->epoch; epoch <= o->max_epochs; ++epoch) {
+    PMFCHK(pmf_epoch_begin(c, o));
+    PMFCHK(pmf_epoch_step_local(c, o));
+    PMFCHK(pmf_epoch_step_shared(c, o));
+    PMFCHK(pmf_epoch_loss(c, &loss, nullptr));
+    if (res->loss_trace && n < res->trace_cap) res->loss_trace[n] = loss;
+    ++n;
+    last_epoch = epoch;
+    if (o->verbosity > 0 && o->print_iter > 0 && (epoch % o->print_iter == 0))
+      fprintf(stderr, "(%d) Loss=%.8g\n", epoch, loss);
+    if (!std::isfinite(loss)) { term = PMF_TERM_NONFINITE; break; }
+    if (n > 1) {
+      const double diff = prev - loss;
+      if (diff < 0) { term = PMF_TERM_LOSS_INCREASE; break; }
+      int which = -1;
+      if (std::fabs(diff) < o->abs_tol) which = PMF_TERM_ABS_TOL;
+      else if (std::fabs(diff / loss) < o->rel_tol) which = PMF_TERM_REL_TOL;
+      if (which >= 0) {
+        if (++tol_iters >= tol_max) { term = which; break; }
+      } else {
+        tol_iters = 0;
+      }
+    }
+    prev = loss;
+  }
+  res->term_code = term;
+  res->epochs = last_epoch;
+  res->n_trace = res->loss_trace ? std::min(n, res->trace_cap) : 0;
+  res->final_loss = loss;
+  res->seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  return 0;
+}
+
+extern "C" int pmf_grad_device_ptr(pmf_ctx *c, int which, void **ptr, int64_t *n) {
+  PMFCHK(ctx_bind(c));
+  if (which < 0 || which > 5) return pmf_fail("bad parameter id %d", which);
+  if (ptr) *ptr = c->P[which].g;
+  if (n) *n = c->P[which].n;
+  return 0;
+}
+
+extern "C" int pmf_get_grad(pmf_ctx *c, int which, int view, float *out) {
+  PMFCHK(ctx_bind(c));
+  if (which < 0 || which > 5) return pmf_fail("bad parameter id %d", which);
+  HIPCHK(hipStreamSynchronize(c->stream));
+  if (which <= 1) return download_padded(c, out, c->P[which].g, which == 0 ? c->M : c->N);
+  if (which <= 3) {
+    HIPCHK(hipMemcpy(out, c->P[which].g, sizeof(float) * (size_t)c->N, hipMemcpyDeviceToHost));
+    return 0;
+  }
+  if (view < 0 || view >= c->n_bv) return pmf_fail("batch view %d out of range", view);
+  const int64_t off = c->val_off[view], n = c->val_off[view + 1] - off;
+  HIPCHK(hipMemcpy(out, c->P[which].g + off, sizeof(float) * (size_t)n, hipMemcpyDeviceToHost));
+  return 0;
+}
+
+static int run_forward(pmf_ctx *c, float *Zdev, int synth, uint64_t seed, float noise, float frac_nan) {
+  PMFCHK(check_ready(c));
+  PMFCHK(prepare(c));
+  ForwardArgs a;
+  memset(&a, 0, sizeof(a));
+  a.X = c->P[0].p; a.Y = c->P[1].p; a.colp = c->colp; a.bor = c->bor; a.btab = c->btab; a.Z = Zdev;
+  a.M = c->M; a.N = c->N; a.Kp = c->Kp; a.K = c->K; a.synth = synth; a.seed = seed; a.noise = noise; a.frac_nan = frac_nan;
+  for (int v = 0; v < c->n_bv; ++v) a.views[v] = c->views[v];
+  if (c->N > 2147483647ll) return pmf_fail("N too large for the forward kernel grid");
+  hipLaunchKernelGGL(k_forward, dim3((unsigned)((c->M + 255) / 256), (unsigned)c->N), dim3(256), 0, c->stream, a);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+extern "C" int pmf_forward(pmf_ctx *c, float *Z_host) {
+  PMFCHK(ctx_bind(c));
+  if (!Z_host) return pmf_fail("null output");
+  const size_t bytes = sizeof(float) * (size_t)(c->M * c->N);
+  float *Z = nullptr;
+  HIPCHK(hipMalloc((void **)&Z, bytes));
+  int rc = run_forward(c, Z, 0, 0, 0.f, 0.f);
+  if (rc == 0) {
+    hipError_t e = hipMemcpyAsync(Z_host, Z, bytes, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e != hipSuccess) rc = pmf_fail("copy back failed: %s", hipGetErrorString(e));
+  }
+  (void)hipFree(Z);
+  return rc;
+}
+
+extern "C" int pmf_synth_data(pmf_ctx *c, uint64_t seed, float noise, float frac_nan) {
+  PMFCHK(ctx_bind(c));
+  if (!c->D) return pmf_fail("data buffer not allocated (pmf_set_data_device(ctx, NULL, M, N, store))");
+  PMFCHK(run_forward(c, c->D, 1, seed, noise, frac_nan));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+extern "C" int pmf_kernel_time(pmf_ctx *c, double *mean_ms, int64_t *launches, int reset) {
+  PMFCHK(ctx_bind(c));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  harvest_events(c);
+  if (mean_ms) *mean_ms = c->kernel_launches > 0 ? c->kernel_ms_sum / (double)c->kernel_launches : 0.0;
+  if (launches) *launches = c->kernel_launches;
+  if (reset) { c->kernel_ms_sum = 0.0; c->kernel_launches = 0; }
+  return 0;
+}

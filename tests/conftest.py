@@ -1,0 +1,27 @@
+import sys
+from pathlib import Path
+
+import pytest
+
+ROOT = Path(__file__).resolve().parent.parent
+for p in (str(ROOT), str(ROOT / "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run by the driver with -m gpu)")
+
+
+@pytest.fixture(scope="session")
+def pkg():
+    import pmf_import
+    return pmf_import.load()
+
+
+@pytest.fixture(scope="session")
+def ctx(pkg):
+    """One HIP context for the whole GPU session (fails loudly if libpmf_hip.so / a gfx950 GPU is missing)."""
+    c = pkg.Context(0)
+    yield c
+    c.close()
