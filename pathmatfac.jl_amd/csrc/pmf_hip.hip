@@ -444,8 +444,8 @@ __device__ __forceinline__ uint64_t splitmix64(uint64_t x) {
 }
 __global__ __launch_bounds__(256) void k_forward(const ForwardArgs a) {
   // block: 256 consecutive rows of one column -> coalesced stores along i
-  const int64_t j = blockIdx.y;
-  const int64_t i = blockIdx.x * 256ll + threadIdx.x;
+  const int64_t j = blockIdx.x;
+  const int64_t i = blockIdx.y * 256ll + threadIdx.x;
   __shared__ float ys[128];
   for (int k = threadIdx.x; k < a.Kp; k += 256) ys[k] = a.Y[j * a.Kp + k];
   __syncthreads();
@@ -1329,8 +1329,8 @@ static int run_forward(pmf_ctx *c, float *Zdev, int synth, uint64_t seed, float 
   a.X = c->P[0].p; a.Y = c->P[1].p; a.colp = c->colp; a.bor = c->bor; a.btab = c->btab; a.Z = Zdev;
   a.M = c->M; a.N = c->N; a.Kp = c->Kp; a.K = c->K; a.synth = synth; a.seed = seed; a.noise = noise; a.frac_nan = frac_nan;
   for (int v = 0; v < c->n_bv; ++v) a.views[v] = c->views[v];
-  if (c->N > 2147483647ll) return pmf_fail("N too large for the forward kernel grid");
-  hipLaunchKernelGGL(k_forward, dim3((unsigned)((c->M + 255) / 256), (unsigned)c->N), dim3(256), 0, c->stream, a);
+  if ((c->M + 255) / 256 > 65535) return pmf_fail("M too large for the forward kernel grid");
+  hipLaunchKernelGGL(k_forward, dim3((unsigned)c->N, (unsigned)((c->M + 255) / 256)), dim3(256), 0, c->stream, a);
   HIPCHK(hipGetLastError());
   return 0;
 }
