@@ -6,6 +6,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -620,10 +621,10 @@ static int data_shape_changed(pmf_ctx *c, int64_t M, int64_t N) {
   return 0;
 }
 
-// The device copy of D is M x Npad with Npad = roundup(N, PMF_BN); the pad columns hold NaN (= missing), so
+// The device copy of D is M x Npad with Npad = roundup(N, PMF_DPAD); the pad columns hold NaN (= missing), so
 // the fused kernel needs no column bounds checks.
 static int alloc_padded_D(pmf_ctx *c, int64_t M, int64_t N) {
-  const int64_t Npad = (N + PMF_BN - 1) / PMF_BN * PMF_BN;
+  const int64_t Npad = (N + PMF_DPAD - 1) / PMF_DPAD * PMF_DPAD;
   if (44.0 * (double)M * 4.0 >= 4294967296.0) return pmf_fail("M=%lld rows per device exceeds the 32-bit tile offset range", (long long)M);
   if (!(c->own_D && c->D && c->D_M == M && c->D_Npad == Npad)) {
     if (c->own_D) dev_free(&c->D);
@@ -655,7 +656,7 @@ extern "C" int pmf_set_data_device(pmf_ctx *c, const void *D, int64_t M, int64_t
   PMFCHK(ctx_bind(c));
   if (store != PMF_STORE_F32) return pmf_fail("only PMF_STORE_F32 is implemented");
   PMFCHK(data_shape_changed(c, M, N));
-  if (D != nullptr && N % PMF_BN == 0 && 44.0 * (double)M * 4.0 < 4294967296.0) {
+  if (D != nullptr && N % PMF_DPAD == 0 && 44.0 * (double)M * 4.0 < 4294967296.0) {
     // adopt the caller's matrix in place (no pad columns needed)
     if (c->own_D) dev_free(&c->D);
     c->own_D = false;
@@ -1100,6 +1101,10 @@ static int launch_fused(pmf_ctx *c, bool want_gx, bool want_gy) {
   a.M = c->M; a.N = c->N; a.n_macro = n_macro; a.seg_cols = tiles_per_seg * PMF_BN; a.n_cseg = (int)n_cseg;
   a.gx_atomic = n_cseg > 1;
   a.want_gx = want_gx; a.want_gy = want_gy;
+  {
+    const char *dbg = getenv("PMF_DEBUG_FLAGS");
+    a.dbg = dbg ? atoi(dbg) : 0;
+  }
   for (int v = 0; v < c->n_bv; ++v) a.views[v] = c->views[v];
   const int grid = (int)std::min<int64_t>(n_macro, c->n_cu);
   const bool batch = c->n_bv > 0;
