@@ -165,11 +165,9 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             rows, ep = 3000, 3
-            try:
-                ncores = len(os.sched_getaffinity(0))
-            except AttributeError:
-                ncores = os.cpu_count()
             t_epoch = cpu_baseline(N, K, rows, ep, seed)
+            from oracle import pmf_oracle as po
+            ncores = int(po.get_lib(32).lib.o_num_threads())     # OpenMP threads the oracle actually used
             out["cpu_baseline"] = {"value": 1.0 / (t_epoch * M / rows), "unit": "iters/s", "cores": ncores,
                                    "kind": "port",
                                    "sample": f"CPU oracle (float build, OpenMP) on {rows} of {M} rows x {N} cols, K={K}, "

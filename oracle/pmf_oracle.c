@@ -696,3 +696,10 @@ int o_fit(o_model *mdl, const o_opts *opt, o_optstate *st, double *trace, int32_
 }
 
 int o_sizeof_real(void) { return (int)sizeof(real); }
+
+#ifdef _OPENMP
+#include <omp.h>
+int o_num_threads(void) { return omp_get_max_threads(); }
+#else
+int o_num_threads(void) { return 1; }
+#endif
