@@ -163,6 +163,16 @@ def main():
                          "hbm_stream_GBps": 4.0 * Ml * N / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0},
             "loss_first": losses[0], "loss_last": losses[-1],
         }
+        # HBM traffic of the dominant kernel: measured offline with rocprofv3 PMC passes (scripts/profile.sh) and
+        # committed under profiles/; reported only when it was measured for exactly this workload
+        try:
+            tr = json.loads((ROOT / "profiles" / "traffic_latest.json").read_text())
+            wl = tr["workload"]
+            if (wl["M"], wl["N"], wl["K"], wl["n_gpus"]) == (M, N, K, world):
+                out["roofline"]["traffic"] = tr["hbm_read_bytes_per_launch"] + tr["hbm_write_bytes_per_launch"]
+                out["roofline"]["traffic_source"] = tr["source"]
+        except (OSError, KeyError, ValueError):
+            pass
         if world == 1 and not args.no_cpu_baseline:
             rows, ep = 3000, 3
             t_epoch = cpu_baseline(N, K, rows, ep, seed)
