@@ -195,6 +195,18 @@ int pmf_get_grad(pmf_ctx *ctx, int which, int view, float *out);
 /* MF.forward(matfac) (src/simulate_params.jl:247): Z = layers(X'Y) for all local rows, M x N column-major */
 int pmf_forward(pmf_ctx *ctx, float *Z_host);
 
+/* Masked column statistics for the closed-form initialisers that sit between the GD stages (local rows only; a
+ * multi-GPU host sums them across ranks).  All outputs are optional (NULL = not wanted).
+ *   col_n[N]        MF.column_nonnan                         (src/fit.jl:140, 447; src/regularizers.jl:765)
+ *   col_sum, col_sumsq[N]  -> MF.batched_column_nanvar       (src/regularizers.jl:766)
+ *   col_sqerr[N]    MF.link_col_sqerr                        (src/fit.jl:138, 444)
+ *   col_ssq_grad[N] MF.batched_column_ssq_grads              (src/fit.jl:166)
+ *   batch_count / batch_sqerr: ba_map(isfinite), ba_map(MF.sqerr_func) (src/fit.jl:332, 355, 454-456;
+ *                   src/batch_array.jl:305-334), flat over (view, column, batch) like logdelta / theta
+ * use_factors = 0 evaluates the model with X'Y = 0, which is how the reference calls these (src/fit.jl:133-136, 160-163). */
+int pmf_stats(pmf_ctx *ctx, int use_factors, float *col_n, float *col_sum, float *col_sumsq, float *col_sqerr,
+              float *col_ssq_grad, float *batch_count, float *batch_sqerr);
+
 /* per-launch timing of the fused data-pass kernel (HIP events on the library's stream): mean milliseconds and
  * number of launches since the last reset */
 int pmf_kernel_time(pmf_ctx *ctx, double *mean_ms, int64_t *launches, int reset);

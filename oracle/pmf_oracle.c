@@ -695,6 +695,58 @@ int o_fit(o_model *mdl, const o_opts *opt, o_optstate *st, double *trace, int32_
   return term;
 }
 
+/* ------------------------------------------------------------------------- */
+/* Masked column / (batch, column) statistics used by the closed-form initialisers between the GD stages.
+ * The MatFac helpers they restate are un-vendored; the formulas are SELF-SPECIFIED from their call sites:
+ *   col_n      MF.column_nonnan            (fit.jl:140, 447; regularizers.jl:765)   #finite entries per column
+ *   col_sum/sq -> MF.batched_column_nanvar (regularizers.jl:766)
+ *   col_sqerr  MF.link_col_sqerr           (fit.jl:138, 444)    sum_i (invlink(z_ij) - D_ij)^2 over finite entries
+ *   col_ssqg   MF.batched_column_ssq_grads (fit.jl:166)         sum_i (dloss/dz)^2
+ *   b_n, b_sqerr  ba_map(isfinite) / ba_map(MF.sqerr_func)      (fit.jl:332, 355, 454-456; batch_array.jl:305-334)
+ * use_factors = 0: X'Y treated as 0 (the reference zeroes X and Y around these calls, fit.jl:133-136, 160-163). */
+void o_stats(const o_model *mdl, int use_factors, real *col_n, real *col_sum, real *col_sumsq, real *col_sqerr,
+             real *col_ssqg, real *b_n, real *b_sqerr) {
+  const int64_t M = mdl->M, N = mdl->N;
+  real *Z = (real *)calloc((size_t)(M * N), sizeof(real));
+  if (use_factors) o_xty(mdl->X, mdl->Y, mdl->K, 0, M, N, Z);
+  o_layers_forward(mdl, Z, NULL, 0, M);
+  int32_t *kind = (int32_t *)malloc(sizeof(int32_t) * (size_t)N);
+  for (int32_t r = 0; r < mdl->n_noise; ++r)
+    for (int64_t j = mdl->nz_start1[r] - 1; j < mdl->nz_stop1[r]; ++j) kind[j] = mdl->nz_kind[r];
+  real *R2 = (real *)calloc((size_t)(M * N), sizeof(real));   /* squared residuals (0 where missing) */
+  real *F = (real *)calloc((size_t)(M * N), sizeof(real));    /* finite indicator */
+  for (int64_t j = 0; j < N; ++j) {
+    double n = 0, s1 = 0, s2 = 0, se = 0, sg = 0;
+    for (int64_t i = 0; i < M; ++i) {
+      const float yf = mdl->D[i + M * j];
+      if (!isfinite(yf)) continue;
+      const real y = (real)yf, z = Z[i + M * j];
+      real pred;
+      if (kind[j] == O_KIND_NORMAL) pred = z;
+      else if (kind[j] == O_KIND_BERNOULLI) pred = o_sigmoid(z);
+      else pred = R_EXP(z);
+      const real g = mdl->col_weight[j] * (pred - y);
+      const real r = pred - y;
+      n += 1; s1 += y; s2 += (double)y * y; se += (double)r * r; sg += (double)g * g;
+      R2[i + M * j] = r * r;
+      F[i + M * j] = 1;
+    }
+    if (col_n) col_n[j] = (real)n;
+    if (col_sum) col_sum[j] = (real)s1;
+    if (col_sumsq) col_sumsq[j] = (real)s2;
+    if (col_sqerr) col_sqerr[j] = (real)se;
+    if (col_ssqg) col_ssqg[j] = (real)sg;
+  }
+  if (mdl->has_batch && mdl->n_bv > 0 && b_n && b_sqerr) {
+    const int64_t tot = mdl->bv_off[mdl->n_bv];
+    memset(b_n, 0, sizeof(real) * (size_t)tot);
+    memset(b_sqerr, 0, sizeof(real) * (size_t)tot);
+    o_ba_colsums(F, M, M, mdl->n_bv, mdl->bv_start1, mdl->bv_stop1, mdl->bv_nb, mdl->bv_bor, M, mdl->bv_off, b_n);
+    o_ba_colsums(R2, M, M, mdl->n_bv, mdl->bv_start1, mdl->bv_stop1, mdl->bv_nb, mdl->bv_bor, M, mdl->bv_off, b_sqerr);
+  }
+  free(Z); free(kind); free(R2); free(F);
+}
+
 int o_sizeof_real(void) { return (int)sizeof(real); }
 
 #ifdef _OPENMP

@@ -292,6 +292,18 @@ class OracleModel:
         g["data_loss"] = dl.value
         return loss, g
 
+    def stats(self, use_factors=False):
+        L = self.L
+        R = L.np_real
+        out = {k: np.zeros(self.N, R) for k in ("n", "sum", "sumsq", "sqerr", "ssq_grad")}
+        bn, bs = np.zeros(max(self.theta_flat.size, 1), R), np.zeros(max(self.theta_flat.size, 1), R)
+        L.lib.o_stats(C.byref(self.m), int(use_factors), _ptr(out["n"], L.c_real), _ptr(out["sum"], L.c_real),
+                      _ptr(out["sumsq"], L.c_real), _ptr(out["sqerr"], L.c_real), _ptr(out["ssq_grad"], L.c_real),
+                      _ptr(bn, L.c_real), _ptr(bs, L.c_real))
+        out["batch_count"] = self._unflat(bn[:self.theta_flat.size])
+        out["batch_sqerr"] = self._unflat(bs[:self.theta_flat.size])
+        return out
+
     def reset_optimizer(self):
         self.state = None
 

@@ -46,7 +46,7 @@ EXPORTS = [
     "pmf_clear_yreg", "pmf_add_yreg_l2", "pmf_add_yreg_group", "pmf_add_yreg_ard", "pmf_add_yreg_fsard",
     "pmf_set_layer_regs", "pmf_set_optimizer", "pmf_set_lr", "pmf_get_lr", "pmf_reset_optimizer_state",
     "pmf_fit", "pmf_epoch_begin", "pmf_epoch_step_local", "pmf_epoch_step_shared", "pmf_epoch_loss",
-    "pmf_grad_device_ptr", "pmf_get_grad", "pmf_forward", "pmf_kernel_time", "pmf_synth_data",
+    "pmf_grad_device_ptr", "pmf_get_grad", "pmf_forward", "pmf_stats", "pmf_kernel_time", "pmf_synth_data",
 ]
 
 _lib = None
@@ -61,6 +61,13 @@ def load_library(path=None):
     if not p.exists():
         raise PMFError(f"{p} not found: build it with pathmatfac.jl_amd/csrc/build.sh "
                        "(python -c 'import __graft_entry__ as g; g.build()'). There is no CPU fallback.")
+    # PyTorch-ROCm bundles its own libamdhip64; a process must run ONE HIP runtime.  If torch is installed, load it
+    # first so that libpmf_hip.so binds to the same runtime (loading the library first and torch later leaves
+    # torch.cuda unusable).  A host without torch (the Julia shim) simply uses the system ROCm runtime.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = C.CDLL(str(p))
     lib.pmf_last_error.restype = C.c_char_p
     for name in EXPORTS:
@@ -318,6 +325,22 @@ class Context:
         Z = np.zeros((self.M, self.N), np.float32, order="F")
         self._chk(self.lib.pmf_forward(self._h, _fp(Z)))
         return Z
+
+    def stats(self, use_factors=False):
+        """Masked column and (batch, column) statistics (pmf_stats).  Returns a dict of float32 arrays."""
+        N = self.N
+        out = {k: np.zeros(N, np.float32) for k in ("n", "sum", "sumsq", "sqerr", "ssq_grad")}
+        nbt = sum(nb * nv for nb, nv in self.view_shapes)
+        bc, bs = np.zeros(max(nbt, 1), np.float32), np.zeros(max(nbt, 1), np.float32)
+        self._chk(self.lib.pmf_stats(self._h, int(use_factors), _fp(out["n"]), _fp(out["sum"]), _fp(out["sumsq"]),
+                                     _fp(out["sqerr"]), _fp(out["ssq_grad"]), _fp(bc), _fp(bs)))
+        off, cnt, sq = 0, [], []
+        for nb, nv in self.view_shapes:
+            cnt.append(bc[off:off + nb * nv].reshape((nb, nv), order="F").copy())
+            sq.append(bs[off:off + nb * nv].reshape((nb, nv), order="F").copy())
+            off += nb * nv
+        out["batch_count"], out["batch_sqerr"] = cnt, sq
+        return out
 
     def kernel_time(self, reset=False):
         ms, n = C.c_double(0), C.c_int64(0)

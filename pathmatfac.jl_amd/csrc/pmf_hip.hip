@@ -423,6 +423,95 @@ __global__ __launch_bounds__(64) void k_layer_grad(const LayerGradArgs a) {
   if (tid == 0 && a.loss_partial) a.loss_partial[(int64_t)blockIdx.y * gridDim.x + blockIdx.x] = s;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Column / (batch, column) statistics for the closed-form initialisers between the GD stages:
+//   n_j = #finite D_ij, sum, sumsq            -> MF.column_nonnan, MF.batched_column_nanvar (regularizers.jl:765-766)
+//   sqerr_j = sum_i (invlink(z_ij) - D_ij)^2  -> MF.link_col_sqerr (fit.jl:138, 444)      [self-specified, DESIGN.md]
+//   ssqg_j = sum_i (dl/dz)^2                  -> MF.batched_column_ssq_grads (fit.jl:166)
+//   per (batch, column): count, sqerr         -> ba_map(isfinite) / ba_map(MF.sqerr_func) (fit.jl:332, 355, 454-456)
+// use_factors = 0 evaluates z with X'Y = 0 (the reference zeroes X and Y around these calls: fit.jl:133-136, 160-163).
+// Same thread-per-column structure as k_layer_grad; called a handful of times per fit, not per epoch.
+// ------------------------------------------------------------------------------------------------
+struct StatsArgs {
+  const float *D, *X, *Y;
+  const float4 *colp;
+  const int32_t *bor;
+  const float2 *btab;
+  float *col_n, *col_sum, *col_sumsq, *col_sqerr, *col_ssqg;  // N each
+  float *b_n, *b_sqerr;                                       // flat like theta (may be null)
+  int64_t M, N;
+  int Kp, K, rows_per_block, max_nb, use_factors;
+  ViewDesc views[PMF_MAXV];
+  int64_t val_off[PMF_MAXV];
+};
+
+__global__ __launch_bounds__(64) void k_stats(const StatsArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem_st[];
+  float *xs = reinterpret_cast<float *>(smem_st);
+  float *bacc = xs + a.Kp;  // [2][max_nb][64]
+  const int tid = threadIdx.x;
+  const int64_t j = blockIdx.x * 64 + tid;
+  const bool col_ok = j < a.N;
+  const int64_t jc = col_ok ? j : a.N - 1;
+  const int64_t r0 = (int64_t)blockIdx.y * a.rows_per_block;
+  int64_t r1 = r0 + a.rows_per_block;
+  if (r1 > a.M) r1 = a.M;
+  const float4 cp = a.colp[jc];
+  const int meta = __float_as_int(cp.w);
+  const int kind = meta & 3;
+  const int v = (meta >> 2) - 1;
+  const ViewDesc vd = a.views[v >= 0 ? v : 0];
+  for (int e = tid; e < 2 * a.max_nb * 64; e += 64) bacc[e] = 0.f;
+  float sn = 0.f, s1 = 0.f, s2 = 0.f, se = 0.f, sg = 0.f;
+  const float *y = a.Y + jc * a.Kp;
+  for (int64_t i = r0; i < r1; ++i) {
+    float acc = 0.f;
+    if (a.use_factors) {
+      __syncthreads();
+      for (int k = tid; k < a.Kp; k += 64) xs[k] = a.X[i * a.Kp + k];
+      __syncthreads();
+      for (int k = 0; k < a.K; ++k) acc = fmaf(xs[k], y[k], acc);
+    }
+    float dl = 1.f, th = 0.f;
+    int b = -1;
+    if (v >= 0) {
+      b = a.bor[(int64_t)v * a.M + i];
+      if (b >= 0) {
+        const float2 dt = a.btab[vd.tab_off + (jc - vd.c0) * vd.nb + b];
+        dl = dt.x;
+        th = dt.y;
+      }
+    }
+    const float yv = a.D[jc * a.M + i];
+    if (!(fabsf(yv) <= 3.402823466e38f)) continue;
+    const float z = fmaf(acc * cp.x, dl, cp.y + th);
+    float pred, g;
+    if (kind == PMF_NOISE_NORMAL) { pred = z; g = cp.z * (z - yv); }
+    else if (kind == PMF_NOISE_BERNOULLI) { pred = 1.f / (1.f + __expf(-z)); g = cp.z * (pred - yv); }
+    else { pred = __expf(z); g = cp.z * (pred - yv); }
+    const float r = pred - yv;
+    sn += 1.f; s1 += yv; s2 += yv * yv; se += r * r; sg += g * g;
+    if (b >= 0) {
+      bacc[b * 64 + tid] += 1.f;
+      bacc[(a.max_nb + b) * 64 + tid] += r * r;
+    }
+  }
+  if (col_ok) {
+    if (a.col_n) atomicAdd(a.col_n + j, sn);
+    if (a.col_sum) atomicAdd(a.col_sum + j, s1);
+    if (a.col_sumsq) atomicAdd(a.col_sumsq + j, s2);
+    if (a.col_sqerr) atomicAdd(a.col_sqerr + j, se);
+    if (a.col_ssqg) atomicAdd(a.col_ssqg + j, sg);
+    if (v >= 0 && a.b_n) {
+      for (int b = 0; b < vd.nb; ++b) {
+        const int64_t e = a.val_off[v] + (j - vd.c0) * vd.nb + b;
+        atomicAdd(a.b_n + e, bacc[b * 64 + tid]);
+        atomicAdd(a.b_sqerr + e, bacc[(a.max_nb + b) * 64 + tid]);
+      }
+    }
+  }
+}
+
 // Z = layers(X'Y) materialised (MF.forward, simulate_params.jl:247); also used by pmf_synth_data.
 struct ForwardArgs {
   const float *X, *Y;
@@ -1361,6 +1450,48 @@ extern "C" int pmf_synth_data(pmf_ctx *c, uint64_t seed, float noise, float frac
   if (!c->D) return pmf_fail("data buffer not allocated (pmf_set_data_device(ctx, NULL, M, N, store))");
   PMFCHK(run_forward(c, c->D, 1, seed, noise, frac_nan));
   HIPCHK(hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+extern "C" int pmf_stats(pmf_ctx *c, int use_factors, float *col_n, float *col_sum, float *col_sumsq, float *col_sqerr,
+                         float *col_ssq_grad, float *batch_count, float *batch_sqerr) {
+  PMFCHK(ctx_bind(c));
+  PMFCHK(check_ready(c));
+  PMFCHK(prepare(c));
+  const int64_t nbt = c->n_bv > 0 ? c->val_off[c->n_bv] : 0;
+  const size_t nfl = (size_t)(5 * c->N + 2 * nbt);
+  PMFCHK(ensure_scratch(c, sizeof(float) * std::max<size_t>(nfl, 1)));
+  float *buf = (float *)c->scratch;
+  HIPCHK(hipMemsetAsync(buf, 0, sizeof(float) * nfl, c->stream));
+  StatsArgs a;
+  memset(&a, 0, sizeof(a));
+  a.D = c->D; a.X = c->P[0].p; a.Y = c->P[1].p; a.colp = c->colp; a.bor = c->bor; a.btab = c->btab;
+  a.col_n = buf; a.col_sum = buf + c->N; a.col_sumsq = buf + 2 * c->N; a.col_sqerr = buf + 3 * c->N; a.col_ssqg = buf + 4 * c->N;
+  a.b_n = nbt ? buf + 5 * c->N : nullptr;
+  a.b_sqerr = nbt ? buf + 5 * c->N + nbt : nullptr;
+  a.M = c->M; a.N = c->N; a.Kp = c->Kp; a.K = c->K; a.use_factors = use_factors;
+  int max_nb = 1;
+  for (int v = 0; v < c->n_bv; ++v) {
+    a.views[v] = c->views[v];
+    a.val_off[v] = c->val_off[v];
+    max_nb = std::max(max_nb, c->views[v].nb);
+  }
+  a.max_nb = max_nb;
+  const int gx = nblocks(c->N, 64);
+  int64_t gy = std::max<int64_t>(1, std::min<int64_t>((8ll * c->n_cu + gx - 1) / gx, (c->M + 63) / 64));
+  a.rows_per_block = (int)((c->M + gy - 1) / gy);
+  gy = (c->M + a.rows_per_block - 1) / a.rows_per_block;
+  const size_t lds = sizeof(float) * (size_t)(c->Kp + 2 * max_nb * 64);
+  if (lds > 160 * 1024) return pmf_fail("too many row batches per view (%d) for the statistics kernel", max_nb);
+  HIPCHK(hipFuncSetAttribute((const void *)k_stats, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(k_stats, dim3(gx, (unsigned)gy), dim3(64), lds, c->stream, a);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(c->stream));
+  float *outs[5] = {col_n, col_sum, col_sumsq, col_sqerr, col_ssq_grad};
+  for (int q = 0; q < 5; ++q)
+    if (outs[q]) HIPCHK(hipMemcpy(outs[q], buf + (int64_t)q * c->N, sizeof(float) * (size_t)c->N, hipMemcpyDeviceToHost));
+  if (batch_count && nbt) HIPCHK(hipMemcpy(batch_count, a.b_n, sizeof(float) * (size_t)nbt, hipMemcpyDeviceToHost));
+  if (batch_sqerr && nbt) HIPCHK(hipMemcpy(batch_sqerr, a.b_sqerr, sizeof(float) * (size_t)nbt, hipMemcpyDeviceToHost));
   return 0;
 }
 

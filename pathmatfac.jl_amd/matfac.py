@@ -74,8 +74,10 @@ def _batch_views(col_transform):
     return views, ba2, ba4
 
 
-def marshal(mf, ctx):
-    """Host model -> device (parameters, noise model, regularizers).  The data matrix is handled by the caller."""
+def marshal(mf, ctx, with_xreg=True, with_yreg=True):
+    """Host model -> device (parameters, noise model, regularizers).  The data matrix is handled by the caller.
+    A regularizer is only marshalled for a factor that is going to be updated: the loop never evaluates the others
+    (and the reference keeps an X_reg of the wrong shape attached while regressing Y only, src/fit.jl:397-428)."""
     ctx.set_factors(mf.X, mf.Y)
     ct = mf.col_transform
     l1, l3 = ct.unwrapped(1), ct.unwrapped(3)
@@ -86,9 +88,11 @@ def marshal(mf, ctx):
     nm = mf.noise_model
     ctx.set_noise([(r.start, r.stop) for r in nm.col_ranges], list(nm.noises), nm.weights)
     ctx.clear_xreg()
-    mf.X_reg.add_to(ctx, "X")
+    if with_xreg:
+        mf.X_reg.add_to(ctx, "X")
     ctx.clear_yreg()
-    mf.Y_reg.add_to(ctx, "Y")
+    if with_yreg:
+        mf.Y_reg.add_to(ctx, "Y")
     sr = mf.col_transform_reg
     kw = {}
     if isinstance(sr, SequenceReg):
@@ -133,7 +137,7 @@ def fit_(mf, ctx, opt=None, lr=0.01, update_X=False, update_Y=False, update_col_
          keep_history=True, dist=None, group=None, **ignored):
     """MF.fit!(matfac, data; ...) -> history dict with "term_code", "epochs", "loss" (src/fit.jl:24-38, 61-69)."""
     opt = opt if opt is not None else AdaGrad(lr)
-    marshal(mf, ctx)
+    marshal(mf, ctx, with_xreg=update_X, with_yreg=update_Y)
     if opt._bound_ctx != id(ctx):          # a new optimizer object: fresh accumulators (src/fit.jl:55)
         ctx.set_optimizer(**opt.params())
         opt._bound_ctx = id(ctx)

@@ -1,0 +1,121 @@
+"""GPU tests of the "next" rows: column / batch statistics kernel (N1, N2), the closed-form
+initialisers and the batch-effect EM built on it, the FeatureSetARD outer loop (N3) and the full fit! orchestration."""
+import numpy as np
+import pytest
+
+from oracle import fsard_oracle as fo
+from problems import make_problem, rel_err, to_context, to_oracle
+from test_gpu_host import reference_fit_setup
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("use_factors", [False, True])
+@pytest.mark.parametrize("case", [
+    dict(M=301, N=143, K=8, nan_frac=0.15, col_params=True, weights=True),
+    dict(M=420, N=260, K=32, bernoulli_frac=0.2, poisson_frac=0.1, n_views=3, batch_views=2, n_batches=6, nan_frac=0.1,
+         weights=True, col_params=True, scale=0.4),
+])
+def test_statistics_kernel_matches_oracle(ctx, case, use_factors):
+    p = make_problem(seed=31, **case)
+    to_context(p, ctx)
+    st = ctx.stats(use_factors)
+    so = to_oracle(p).stats(use_factors)
+    assert np.array_equal(st["n"], so["n"])                       # counts are exact
+    for k in ("sum", "sumsq", "sqerr", "ssq_grad"):
+        assert rel_err(st[k], so[k]) <= 2e-5, k
+    for v in range(len(p["batch_views"])):
+        assert np.array_equal(st["batch_count"][v], so["batch_count"][v])
+        assert rel_err(st["batch_sqerr"][v], so["batch_sqerr"][v]) <= 2e-5
+
+
+def test_closed_form_initialisers(pkg):
+    rng = np.random.default_rng(32)
+    M, N, K = 200, 60, 5
+    D = (rng.standard_normal((M, N)) * (1 + np.arange(N))[None, :] * 0.1 + 2.0).astype(np.float32)
+    D[rng.random((M, N)) < 0.1] = np.nan
+    model = pkg.make_model(D, K=K, feature_views=[1] * 30 + [2] * 30, rng=rng)
+    Dm = model.data
+    ct = model.matfac.col_transform
+    # init_mu!: M-estimate of a normal column = its (nan)mean
+    pkg.init_mu_(model, lr_mu=0.5, max_epochs=2000, verbosity=0)
+    np.testing.assert_allclose(ct.layers[2].mu, np.nanmean(Dm, axis=0), atol=0.08)   # AdaGrad stops at abs_tol 1e-3 (fit.jl:92)
+    ct.layers[2].mu[...] = np.nanmean(Dm, axis=0)
+    # init_logsigma!: log of the column standard deviation around mu (fit.jl:138-143)
+    pkg.init_logsigma_(model)
+    np.testing.assert_allclose(ct.layers[0].logsigma, np.log(np.sqrt(np.nanmean((Dm - np.nanmean(Dm, 0)) ** 2, axis=0))), rtol=1e-4)
+    # reweight_col_losses!: 1 / (sqrt(sum g^2 / M) * sigma), g = (mu - D) with unit weights (fit.jl:166-176)
+    pkg.reweight_col_losses_(model)
+    g2 = np.nansum((np.nanmean(Dm, 0)[None, :] - Dm).astype(np.float64) ** 2, axis=0)
+    np.testing.assert_allclose(model.matfac.noise_model.weights,
+                               1.0 / (np.sqrt(g2 / M) * np.exp(ct.layers[0].logsigma)), rtol=1e-4)
+    # construct_minimal_regularizer (regularizers.jl:750-774)
+    reg = pkg.construct_minimal_regularizer(model)
+    nn = np.isfinite(Dm).sum(0)
+    var = np.maximum(np.nanvar(Dm.astype(np.float64), axis=0, ddof=1), 1.0 / M)
+    want = K * np.mean(np.exp(ct.layers[0].logsigma) ** 2) / (np.sum(var * nn) / M)
+    assert len(reg.group_idx) == 1 and tuple(reg.group_idx[0]) == (1, N)
+    np.testing.assert_allclose(reg.group_weights[0], want, rtol=1e-4)
+    model.release_device()
+
+
+def test_batch_effect_initialisation_recovers_shifts(pkg):
+    """init_batch_effects! (fit.jl:378-496) on data that is pure (condition mean + batch shift + noise)."""
+    rng = np.random.default_rng(33)
+    M, N = 240, 40
+    conds = ["c1"] * 120 + ["c2"] * 120
+    batches = [f"b{i}" for i in range(4) for _ in range(60)]
+    shift = np.array([0.0, 1.0, -1.0, 0.5])
+    bidx = np.repeat(np.arange(4), 60)
+    D = (rng.standard_normal((M, N)) * 0.3 + shift[bidx][:, None] + 3.0).astype(np.float32)
+    model = pkg.make_model(D, K=3, sample_conditions=conds, feature_views=[1] * N, batch_dict={1: batches}, rng=rng)
+    pkg.init_batch_effects_(model, max_epochs=300, lr_regress=1.0, lr_theta=1.0, lr_mu=0.5, verbosity=0,
+                            batch_em_max_iter=20)
+    ct = model.matfac.col_transform
+    th = ct.layers[3].theta.values[0]
+    assert np.all(np.isfinite(th)) and np.all(np.isfinite(ct.layers[1].logdelta.values[0]))
+    # batches within a condition are identifiable up to the condition mean: b1-b0 = 1, b3-b2 = 1.5
+    assert abs(np.mean(th[1] - th[0]) - 1.0) < 0.15 and abs(np.mean(th[3] - th[2]) - 1.5) < 0.15
+    assert abs(np.mean(np.exp(ct.layers[0].logsigma)) - 0.3) < 0.1
+    model.release_device()
+
+
+def test_update_A_matches_numpy_restatement(pkg):
+    rng = np.random.default_rng(34)
+    K, N, L = 4, 30, 5
+    sets = [[list(range(1 + 3 * l, 4 + 3 * l)) for l in range(L)], [list(range(16 + 3 * l, 19 + 3 * l)) for l in range(L)]]
+    reg = pkg.regularizers.construct_featureset_ard(K, list(range(1, N + 1)), [1] * 15 + [2] * 15, sets, lr=0.05)
+    Y = (rng.standard_normal((K, N)) * 0.05).astype(np.float32)
+    Y[0, :3] += 1.0                                       # factor 1 loads on set 1 of view 1
+    pkg.update_lambda_(reg, Y)
+    reg.lambda_ = tuple((l * 1e-3).astype(np.float32) for l in reg.lambda_)   # weak L1 so that A stays non-trivial
+    lam = [l.copy() for l in reg.lambda_]
+    pkg.update_A_(reg, Y, max_epochs=200, term_iter=50, verbosity=0)
+    for v, cr in enumerate(reg.col_ranges):
+        A = np.zeros((L, K))
+        ssq = np.full((L, K), 1e-8)
+        fo.update_A_inner(A, reg.S[v].astype(np.float64), Y[:, cr.slice0()].astype(np.float64),
+                          reg.alpha[cr.slice0()].astype(np.float64), float(reg.alpha0), float(reg.v0), float(reg.lr),
+                          lam[v].astype(np.float64), ssq, max_epochs=200, term_iter=50)
+        assert rel_err(reg.A[v], A) < 5e-3
+        beta = (float(reg.alpha0) - 1) * (float(reg.v0) + A.T @ reg.S[v].astype(np.float64))
+        assert rel_err(reg.beta[:, cr.slice0()], beta) < 5e-3      # featureset_ard.jl:292
+    assert max(float(A.max()) for A in reg.A) > 0          # a non-trivial assignment matrix was compared
+
+
+def test_full_fit_orchestration_featureset_ard(pkg):
+    """fit!(model) end to end (fit.jl:923-1018) on the reference's fit_tests setup (runtests.jl:1324-1346)."""
+    model = reference_fit_setup(pkg, seed=3)
+    X_start, Y_start = model.matfac.X.copy(), model.matfac.Y.copy()
+    ld_start = [v.copy() for v in model.matfac.col_transform.layers[1].logdelta.values]
+    hist = pkg.fit_(model, verbosity=0, lr=0.05, max_epochs=300, rel_tol=1e-5, abs_tol=1e-5, fsard_term_rtol=1e-3,
+                    fsard_max_iter=3, fsard_max_A_iter=100, keep_history=True)
+    mf = model.matfac
+    assert not np.allclose(mf.X, X_start) and not np.allclose(mf.Y, Y_start)            # runtests.jl:1340-1341
+    assert not all(np.allclose(a, b) for a, b in zip(ld_start, mf.col_transform.layers[1].logdelta.values))  # :1342
+    assert np.all(np.isfinite(mf.X)) and np.all(np.isfinite(mf.Y))
+    names = [d.get("name") for d in hist]
+    assert names[0] == "start" and names[-1] == "finish" and "reorder_factors" in names
+    ssq = np.sum(mf.Y.astype(np.float64) ** 2, axis=1)
+    assert np.all(np.diff(ssq) <= 1e-6)                                                  # reorder_by_importance!
+    model.release_device()
