@@ -69,7 +69,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
-    if world > 1:
+    force_dist = os.environ.get("PMF_FORCE_DIST", "0") == "1"   # exercise the RCCL path with a 1-rank group (testing)
+    if world > 1 or force_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
@@ -110,18 +111,19 @@ def main():
     ctx.add_yreg_fsard(np.full(N, 1.001, np.float32), beta)
     ctx.set_optimizer("adagrad", lr=0.05)
     o = ctx.make_opts(update_X=True, update_Y=True)
-    gY = parallel.grad_tensor(ctx, "Y") if world > 1 else None
+    use_dist = world > 1 or force_dist
+    gY = parallel.grad_tensor(ctx, "Y") if use_dist else None
     loss_buf = torch.zeros(1, dtype=torch.float64, device="cuda")
 
     def step():
         ctx.epoch_begin(o)
-        work = dist.all_reduce(gY, async_op=True) if world > 1 else None
+        work = dist.all_reduce(gY, async_op=True) if use_dist else None
         ctx.epoch_step_local(o)
         if work is not None:
             work.wait()
         ctx.epoch_step_shared(o)
         local, shared = ctx.epoch_loss()
-        if world > 1:
+        if use_dist:
             loss_buf[0] = local - shared
             dist.all_reduce(loss_buf)
             return float(loss_buf.item()) + shared
@@ -129,17 +131,17 @@ def main():
 
     losses = [step() for _ in range(args.warmup)]
     ctx.kernel_time(reset=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         losses.append(step())
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
@@ -184,7 +186,7 @@ def main():
                                              f"{ep} epochs timed ({t_epoch:.2f} s/epoch on the sample), scaled by {M}/{rows}"}
         print(json.dumps(out), flush=True)
     ctx.close()
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 
