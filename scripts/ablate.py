@@ -43,6 +43,10 @@ t("no epilogue", 4, True, True)
 t("no flush", 8, True, True)
 t("no adds+flush", 9, True, True)
 t("no adds/loads/epi/flush", 15, True, True)
+t("no B2 barrier (wrong results)", 16, True, True)
+t("no B2, no reduce/flush", 25, True, True)
+t("no slab writes", 32, True, True)
+t("skeleton w/o B2, slab writes", 15 + 16 + 32, True, True)
 t("forward+GEMM2 only", 0, True, False)
 t("forward+GEMM3 only", 0, False, True)
 t("forward only", 0, False, False)
