@@ -33,3 +33,11 @@ print(f'in-kernel clock (s_memtime / s_memrealtime x 100 MHz, median over waves)
 print(f"{M}x{N} K={K}: kernel {ms:.3f} ms (stamped build), {st.shape[0]} waves; cycles per wave {st.sum(1).mean():.3g}")
 for q, nm in enumerate(names):
     print(f"  {nm:24s} {st[:, q].sum()/tot*100:6.2f} %")
+# per-wave-slot view: do the two waves of a SIMD (w and w+4?) behave differently?
+full = buf.reshape(-1, 8, 16).astype(np.float64)
+full = full[full[:, :, :14].sum((1, 2)) > 0]
+print("wave  total(Mcyc)  B1wait%  GEMM2%  GEMM3%  forward%  loop%")
+for w in range(8):
+    r = full[:, w, :14]
+    t = r.sum()
+    print(f"  {w}   {r.sum(1).mean()/1e6:8.2f}   {r[:, 6].sum()/t*100:6.2f}  {r[:, 3].sum()/t*100:6.2f}  {r[:, 4].sum()/t*100:6.2f}  {r[:, 8].sum()/t*100:6.2f}  {r[:, 0].sum()/t*100:6.2f}")
