@@ -36,8 +36,8 @@ for q, nm in enumerate(names):
 # per-wave-slot view: do the two waves of a SIMD (w and w+4?) behave differently?
 full = buf.reshape(-1, 8, 16).astype(np.float64)
 full = full[full[:, :, :14].sum((1, 2)) > 0]
-print("wave  total(Mcyc)  B1wait%  GEMM2%  GEMM3%  forward%  loop%")
+print("wave  total(Mcyc)  barrier%  epi0%  GEMM2%  GEMM3%  stage%  Yhalf%  loop%")
 for w in range(8):
     r = full[:, w, :14]
     t = r.sum()
-    print(f"  {w}   {r.sum(1).mean()/1e6:8.2f}   {r[:, 6].sum()/t*100:6.2f}  {r[:, 3].sum()/t*100:6.2f}  {r[:, 4].sum()/t*100:6.2f}  {r[:, 8].sum()/t*100:6.2f}  {r[:, 0].sum()/t*100:6.2f}")
+    print(f"  {w}   {r.sum(1).mean()/1e6:8.2f}   {r[:, 6].sum()/t*100:6.2f}  {r[:, 1].sum()/t*100:6.2f}  {r[:, 3].sum()/t*100:6.2f}  {r[:, 4].sum()/t*100:6.2f}  {r[:, 5].sum()/t*100:6.2f}  {r[:, 8].sum()/t*100:6.2f}  {r[:, 0].sum()/t*100:6.2f}")
