@@ -61,6 +61,9 @@ struct pmf_ctx {
   float *D = nullptr;  // tile-major copy of the data matrix (pmf_d_off), always library-owned
   bool own_D = false;
   int64_t D_M = 0, D_Npad = 0, nRB = 0;
+  uint32_t *tflags = nullptr;     // per 32x32 tile of D: 1 = all 1024 entries finite (fast epilogue path of the fused kernel)
+  int64_t tflags_cap = 0;
+  bool tflags_valid = false;
   int store = PMF_STORE_F32;
   ParamBuf P[6];  // X, Y, logsigma, mu, logdelta, theta
   // batch views
@@ -662,6 +665,7 @@ extern "C" int pmf_destroy(pmf_ctx *c) {
   (void)hipStreamSynchronize(c->stream);
   for (auto &b : c->P) param_free(b);
   if (c->own_D) dev_free(&c->D);
+  dev_free(&c->tflags);
   dev_free(&c->bor); dev_free(&c->btab); dev_free(&c->d_val_view);
   dev_free(&c->colmeta); dev_free(&c->colw); dev_free(&c->colp);
   dev_free(&c->ard_alpha); dev_free(&c->ard_beta);
@@ -734,6 +738,7 @@ static int alloc_tiled_D(pmf_ctx *c, int64_t M, int64_t N) {
     c->D_Npad = Npad;
     c->nRB = nRB;
   }
+  c->tflags_valid = false;
   k_fill<<<(int)std::min<int64_t>(nblocks(nfl, 256), 65536), 256, 0, c->stream>>>(c->D, nfl, __builtin_nanf(""));
   HIPCHK(hipGetLastError());
   return 0;
@@ -741,6 +746,7 @@ static int alloc_tiled_D(pmf_ctx *c, int64_t M, int64_t N) {
 
 static int tile_from_device(pmf_ctx *c, const float *src, int64_t col0, int64_t ncols) {
   const int64_t n = c->M * ncols;
+  c->tflags_valid = false;
   k_tile_D<<<nblocks(n, 256), 256, 0, c->stream>>>(src, c->M, col0, ncols, c->D, c->nRB);
   HIPCHK(hipGetLastError());
   return 0;
@@ -1150,6 +1156,32 @@ static int prepare(pmf_ctx *c) {
   return 0;
 }
 
+// One workgroup per 32x32 tile of the tile-major D: flag = 1 iff all 1024 entries are finite.  The fused kernel takes
+// its packed-math epilogue (no per-entry missing-value mask) on flagged tiles.  Recomputed lazily whenever D changes.
+__global__ void k_tile_flags(const float *__restrict__ D, int64_t ntiles, uint32_t *__restrict__ flags) {
+  const int64_t t = blockIdx.x;
+  if (t >= ntiles) return;
+  const float4 v = reinterpret_cast<const float4 *>(D + t * 1024)[threadIdx.x];   // 256 threads x 16 B
+  const bool ok = fabsf(v.x) <= 3.402823466e38f && fabsf(v.y) <= 3.402823466e38f && fabsf(v.z) <= 3.402823466e38f &&
+                  fabsf(v.w) <= 3.402823466e38f;
+  const int all_ok = __syncthreads_and(ok ? 1 : 0);
+  if (threadIdx.x == 0) flags[t] = all_ok ? 1u : 0u;
+}
+
+static int ensure_tile_flags(pmf_ctx *c) {
+  if (c->tflags_valid) return 0;
+  const int64_t ntiles = c->nRB * (c->D_Npad / 32);
+  if (ntiles > c->tflags_cap) {
+    PMFCHK(dev_alloc(&c->tflags, (size_t)ntiles, false));
+    c->tflags_cap = ntiles;
+  }
+  if (ntiles > 0x7fffffff) return pmf_fail("too many tiles");
+  k_tile_flags<<<(unsigned)ntiles, 256, 0, c->stream>>>(c->D, ntiles, c->tflags);
+  HIPCHK(hipGetLastError());
+  c->tflags_valid = true;
+  return 0;
+}
+
 // gY = sum over the workgroups that visited a column's segment of their private slabs, in workgroup order (fixed
 // summation order: grad(Y) is bitwise reproducible).  Work unit u = cs * n_rp + rp belongs to workgroup g iff
 // g*n/G <= u < (g+1)*n/G (pmf_fused_kernel).
@@ -1240,8 +1272,10 @@ static int launch_fused(pmf_ctx *c, bool want_gx, bool want_gy) {
     PMFCHK(dev_alloc(&c->gy_slabs, (size_t)grid * (size_t)slab_stride, false));   // never read before written
     c->gy_slabs_cap = (size_t)grid * (size_t)slab_stride;
   }
+  PMFCHK(ensure_tile_flags(c));
   FusedArgs a;
   memset(&a, 0, sizeof(a));
+  a.tflags = c->tflags;
   a.D = c->D; a.X = c->P[0].p; a.Y = c->P[1].p; a.gX = c->P[0].g; a.gY = c->P[1].g;
   a.colp = c->colp; a.bor = c->bor; a.btab = c->btab; a.loss_partial = c->loss_partial;
   a.nRB = c->nRB; a.gy_slabs = c->gy_slabs; a.slab_stride = slab_stride; a.n_rp = n_rp;
@@ -1520,6 +1554,7 @@ extern "C" int pmf_forward(pmf_ctx *c, float *Z_host) {
 extern "C" int pmf_synth_data(pmf_ctx *c, uint64_t seed, float noise, float frac_nan) {
   PMFCHK(ctx_bind(c));
   if (!c->D) return pmf_fail("data buffer not allocated (pmf_set_data_device(ctx, NULL, M, N, store))");
+  c->tflags_valid = false;
   PMFCHK(run_forward(c, c->D, 1, seed, noise, frac_nan, c->nRB));
   HIPCHK(hipStreamSynchronize(c->stream));
   return 0;
