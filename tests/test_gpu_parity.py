@@ -87,6 +87,10 @@ CASES = {
                           weights=True, col_params=True, scale=0.4),
     "tiny": dict(M=5, N=7, K=2),
     "one_row_panel_many_cols": dict(M=33, N=1500, K=16, nan_frac=0.02),
+    # more work units than workgroups: a workgroup visits several row panels of one column segment (its private gY
+    # slab accumulates by read-modify-write) and some workgroups cross a segment boundary; no missing values, so
+    # interior tiles take the packed-math epilogue
+    "many_panels_two_segments": dict(M=70000, N=600, K=8, xreg="l2", weights=True, col_params=True),
 }
 
 
@@ -233,3 +237,47 @@ def test_gaussian_gradient_is_linear_in_data_at_full_size(ctx):
     Zr = X[:, rows].astype(np.float64).T @ Yd
     gxr = Yd @ (w[None, :] * (Zr - D1[rows])).T
     assert rel_err(gx1[:, rows], gxr) <= GRAD_TOL
+
+
+def test_all_finite_tiles_and_masked_tiles_agree_with_oracle(ctx):
+    """The fused kernel has two epilogues: packed math on 32x32 tiles whose entries are all finite (flag computed
+    when D is laid out) and the general masked path elsewhere.  A matrix with a handful of NaN / Inf entries
+    exercises both in one launch; non-finite entries contribute no loss and no gradient (transform.jl:55-57)."""
+    p = make_problem(seed=21, M=300, N=200, K=16, weights=True, col_params=True)
+    D = p["D"].copy()
+    assert np.isfinite(D).all()
+    for (i, j, v) in [(3, 5, np.nan), (40, 70, np.inf), (41, 70, -np.inf), (299, 199, np.nan), (130, 33, np.nan)]:
+        D[i, j] = v
+    p["D"] = D
+    to_context(p, ctx)
+    loss, g = grads_of(ctx, p, update_X=True, update_Y=True)
+    m = to_oracle(p)
+    m.m.n_xreg = 0
+    m.m.n_yreg = 0
+    _, go = m.loss_and_grads(update_X=True, update_Y=True)
+    assert abs(loss - go["data_loss"]) <= LOSS_RTOL * abs(go["data_loss"])
+    assert rel_err(g["X"], go["X"]) <= GRAD_TOL
+    assert rel_err(g["Y"], go["Y"]) <= GRAD_TOL
+    # changing D must refresh the tile flags: make every entry finite again and compare once more
+    p["D"] = np.where(np.isfinite(D), D, 0.25).astype(np.float32)
+    to_context(p, ctx)
+    loss2, g2 = grads_of(ctx, p, update_X=True, update_Y=True)
+    m2 = to_oracle(p)
+    m2.m.n_xreg = 0
+    m2.m.n_yreg = 0
+    _, go2 = m2.loss_and_grads(update_X=True, update_Y=True)
+    assert abs(loss2 - go2["data_loss"]) <= LOSS_RTOL * abs(go2["data_loss"])
+    assert rel_err(g2["Y"], go2["Y"]) <= GRAD_TOL
+
+
+def test_loss_and_grad_Y_are_bitwise_reproducible(ctx):
+    """grad(Y) and the loss are summed in a fixed order (private per-workgroup slabs + k_gy_reduce, fixed-order loss
+    partials): two evaluations at the same parameters give identical bits, so `loss_increase` decisions
+    (src/fit.jl:63) do not depend on scheduling."""
+    p = make_problem(seed=22, M=3000, N=700, K=64, nan_frac=0.01, weights=True, col_params=True)
+    to_context(p, ctx)
+    l1, g1 = grads_of(ctx, p, update_X=True, update_Y=True)
+    l2, g2 = grads_of(ctx, p, update_X=True, update_Y=True)
+    assert l1 == l2
+    assert np.array_equal(g1["Y"], g2["Y"])
+    assert rel_err(g1["X"], g2["X"]) <= 1e-6      # gX: float atomics across column segments (DESIGN.md section 3)
