@@ -281,3 +281,52 @@ def test_loss_and_grad_Y_are_bitwise_reproducible(ctx):
     assert l1 == l2
     assert np.array_equal(g1["Y"], g2["Y"])
     assert rel_err(g1["X"], g2["X"]) <= 1e-6      # gX: float atomics across column segments
+
+
+def test_headline_size_loss_and_gradient_consistency(ctx):
+    """BASELINE.json's headline configuration (200000 x 50000, K = 64), data generated on the device with 0.1 % missing
+    entries.  Size-independent properties:
+      * the fused kernel's loss equals 0.5 * sum_j w_j * (column sums of squared residuals) from the independent,
+        non-MFMA statistics kernel (pmf_stats);
+      * the gradient is the gradient OF THAT LOSS: for p(e) = p - e*g, (L(0) - L(e)) / (e |g|^2) = 1 - c*e for the
+        (quadratic in each factor) Gaussian loss, so the Richardson combination 2 r(e/2) - r(e) equals 1;
+      * loss and grad(Y) are bitwise reproducible at this size too."""
+    M, N, K = 200000, 50000, 64
+    rng = np.random.default_rng(5)
+    Xt = (rng.standard_normal((K, M)) * 0.3).astype(np.float32)
+    Yt = (rng.standard_normal((K, N)) * 0.3).astype(np.float32)
+    X0 = (Xt + 0.05 * rng.standard_normal((K, M))).astype(np.float32)
+    Y0 = (Yt + 0.05 * rng.standard_normal((K, N))).astype(np.float32)
+    w = (0.5 + rng.random(N)).astype(np.float32)
+    ctx.set_data_device(None, M, N)
+    ctx.set_factors(Xt, Yt)
+    ctx.set_col_params(np.zeros(N, np.float32), np.zeros(N, np.float32))
+    ctx.set_batch_views([])
+    ctx.set_noise([(1, N)], ["normal"], w)
+    ctx.clear_xreg()
+    ctx.clear_yreg()
+    ctx.synth_data(seed=99, noise=0.1, frac_nan=0.001)
+    o = ctx.make_opts(update_X=True, update_Y=True)
+
+    def loss_grad(X, Y, want_grad=True):
+        ctx.set_factors(X, Y)
+        ctx.epoch_begin(o)
+        loss, _ = ctx.epoch_loss()
+        return (loss, ctx.get_grad("X"), ctx.get_grad("Y")) if want_grad else loss
+
+    L0, gX, gY = loss_grad(X0, Y0)
+    L0b, gXb, gYb = loss_grad(X0, Y0)
+    assert L0 == L0b and np.array_equal(gY, gYb)
+    st = ctx.stats(use_factors=True)
+    n_obs = float(st["n"].astype(np.float64).sum())
+    assert abs(n_obs / (M * N) - 0.999) < 2e-4                       # the mask is live at this size
+    L_stats = 0.5 * float(np.sum(w.astype(np.float64) * st["sqerr"].astype(np.float64)))
+    assert abs(L0 - L_stats) <= 5e-5 * L_stats, (L0, L_stats)        # sqerr is accumulated in f32 per column
+    g2 = float(np.sum(gX.astype(np.float64) ** 2) + np.sum(gY.astype(np.float64) ** 2))
+    e = 0.02 * L0 / g2                                               # ~2 % first-order decrease
+    r = []
+    for ee in (e, 0.5 * e):
+        Le = loss_grad((X0 - ee * gX).astype(np.float32), (Y0 - ee * gY).astype(np.float32), want_grad=False)
+        r.append((L0 - Le) / (ee * g2))
+    assert 0.5 < r[0] < 1.0 and r[0] < r[1] < 1.0, r
+    assert abs(2 * r[1] - r[0] - 1.0) <= 5e-3, r
