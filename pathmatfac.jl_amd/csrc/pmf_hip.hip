@@ -1182,25 +1182,38 @@ static int ensure_tile_flags(pmf_ctx *c) {
   return 0;
 }
 
-// gY = sum over the workgroups that visited a column's segment of their private slabs, in workgroup order (fixed
-// summation order: grad(Y) is bitwise reproducible).  Work unit u = cs * n_rp + rp belongs to workgroup g iff
-// g*n/G <= u < (g+1)*n/G (pmf_fused_kernel).
-__global__ void k_gy_reduce(const float *__restrict__ slabs, int64_t stride, int G, int64_t n_units, int64_t n_rp,
-                            int64_t seg_cols, int Kp, int64_t N, float *__restrict__ gY) {
+// gY = sum of the private slabs of the workgroups that visited a column tile, in workgroup order (fixed summation
+// order: grad(Y) is bitwise reproducible).  The work sequence (pmf_fused_kernel) is segment-major, then row panel,
+// then tile; workgroup g owns [g*T/G, (g+1)*T/G).  Inside segment cs (tiles [cs*S, cs*S + n_rp*tps_cs) of the
+// sequence) it touched tile ti iff its range, taken relative to the segment start, contains an index == ti mod tps_cs.
+__global__ void k_gy_reduce(const float *__restrict__ slabs, int64_t stride, int G, int64_t T, int64_t n_rp, int tps,
+                            int n_ct, int n_cseg, int Kp, int64_t N, float *__restrict__ gY) {
   const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= (int64_t)Kp * N) return;
-  const int64_t j = e / Kp;
-  const int64_t cs = j / seg_cols;
+  const int ct = (int)((e / Kp) >> 5);
+  int cs = ct / tps;
+  if (cs > n_cseg - 1) cs = n_cseg - 1;
+  const int tps_cs = cs == n_cseg - 1 ? n_ct - (n_cseg - 1) * tps : tps;
+  const int ti = ct - cs * tps;
+  const int64_t s0 = (int64_t)cs * n_rp * tps, s1 = s0 + n_rp * tps_cs;   // the segment's slice of the sequence
   auto owner = [&](int64_t u) {
-    int64_t g = (u * G) / n_units;
+    int64_t g = (u * G) / T;
     if (g > G - 1) g = G - 1;
-    while (g + 1 < G && (g + 1) * n_units / G <= u) ++g;
-    while (g > 0 && g * n_units / G > u) --g;
+    while (g + 1 < G && (g + 1) * T / G <= u) ++g;
+    while (g > 0 && g * T / G > u) --g;
     return (int)g;
   };
-  const int g_lo = owner(cs * n_rp), g_hi = owner((cs + 1) * n_rp - 1);
+  const int g_lo = owner(s0), g_hi = owner(s1 - 1);
   float acc = 0.f;
-  for (int g = g_lo; g <= g_hi; ++g) acc += slabs[(int64_t)g * stride + e];
+  for (int g = g_lo; g <= g_hi; ++g) {
+    int64_t lo = (int64_t)g * T / G, hi = (int64_t)(g + 1) * T / G;
+    if (lo < s0) lo = s0;
+    if (hi > s1) hi = s1;
+    if (hi <= lo) continue;
+    const int64_t first = (lo - s0) % tps_cs;
+    const int64_t d = (ti - first + tps_cs) % tps_cs;
+    if (d < hi - lo) acc += slabs[(int64_t)g * stride + e];
+  }
   gY[e] = acc;
 }
 
@@ -1257,15 +1270,17 @@ static int launch_fused(pmf_ctx *c, bool want_gx, bool want_gy) {
   int64_t n_cseg = 1;
   const int64_t target = 16ll * c->n_cu;
   if (n_rp < target) n_cseg = std::min<int64_t>((target + n_rp - 1) / n_rp, std::max<int64_t>(1, n_ct / 8));
-  const int64_t tiles_per_seg = (n_ct + n_cseg - 1) / n_cseg;
-  n_cseg = (n_ct + tiles_per_seg - 1) / tiles_per_seg;
-  const int64_t n_macro = n_rp * n_cseg;
-  if (n_macro > c->loss_cap) {
-    PMFCHK(dev_alloc(&c->loss_partial, (size_t)n_macro));
-    c->loss_cap = n_macro;
+  // equal segments of floor(n_ct / n_cseg) tiles; the LAST one takes the remainder (it is longer, never tiny: every
+  // piece of work pays a fixed prologue, so a 5-tile last segment made one workgroup 20 % late)
+  const int64_t tiles_per_seg = std::max<int64_t>(1, n_ct / n_cseg);
+  n_cseg = std::max<int64_t>(1, n_ct / tiles_per_seg);
+  const int64_t n_tiles = n_rp * n_ct;   // the kernel's work items, dealt out in contiguous, balanced ranges
+  const int grid = (int)std::min<int64_t>(n_tiles, (int64_t)c->n_cu * ((NW == 4 && c->KB <= 2) ? 2 : 1));
+  if (grid > c->loss_cap) {
+    PMFCHK(dev_alloc(&c->loss_partial, (size_t)grid));
+    c->loss_cap = grid;
   }
-  c->n_macro = n_macro;
-  const int grid = (int)std::min<int64_t>(n_macro, (int64_t)c->n_cu * ((NW == 4 && c->KB <= 2) ? 2 : 1));
+  c->n_macro = grid;                     // loss partials: one per workgroup
   const int64_t slab_stride = (int64_t)c->Kp * c->N;
   if (want_gy && (size_t)grid * (size_t)slab_stride > c->gy_slabs_cap) {
     dev_free(&c->gy_slabs);
@@ -1279,8 +1294,7 @@ static int launch_fused(pmf_ctx *c, bool want_gx, bool want_gy) {
   a.D = c->D; a.X = c->P[0].p; a.Y = c->P[1].p; a.gX = c->P[0].g; a.gY = c->P[1].g;
   a.colp = c->colp; a.bor = c->bor; a.btab = c->btab; a.loss_partial = c->loss_partial;
   a.nRB = c->nRB; a.gy_slabs = c->gy_slabs; a.slab_stride = slab_stride; a.n_rp = n_rp;
-  a.M = c->M; a.N = c->N; a.n_macro = n_macro; a.seg_cols = tiles_per_seg * PMF_BN; a.n_cseg = (int)n_cseg;
-  a.gx_atomic = n_cseg > 1;
+  a.M = c->M; a.N = c->N; a.n_tiles = n_tiles; a.tps = (int)tiles_per_seg; a.n_ct = (int)n_ct; a.n_cseg = (int)n_cseg;
   a.want_gx = want_gx; a.want_gy = want_gy;
   {
     const char *dbg = getenv("PMF_DEBUG_FLAGS");
@@ -1323,8 +1337,8 @@ static int launch_fused(pmf_ctx *c, bool want_gx, bool want_gy) {
   HIPCHK(hipEventRecord(ev.second, c->stream));   // the events bracket pmf_fused_kernel alone (= rocprofv3's kernel duration)
   if (want_gy && !(a.dbg & 8)) {
     const int64_t ne = slab_stride;
-    k_gy_reduce<<<(unsigned)((ne + 255) / 256), 256, 0, c->stream>>>(c->gy_slabs, slab_stride, grid, n_macro, n_rp, a.seg_cols,
-                                                                    c->Kp, c->N, c->P[1].g);
+    k_gy_reduce<<<(unsigned)((ne + 255) / 256), 256, 0, c->stream>>>(c->gy_slabs, slab_stride, grid, n_tiles, n_rp, a.tps, a.n_ct,
+                                                                    a.n_cseg, c->Kp, c->N, c->P[1].g);
     HIPCHK(hipGetLastError());
   }
   return 0;

@@ -41,3 +41,10 @@ for w in range(8):
     r = full[:, w, :14]
     t = r.sum()
     print(f"  {w}   {r.sum(1).mean()/1e6:8.2f}   {r[:, 6].sum()/t*100:6.2f}  {r[:, 1].sum()/t*100:6.2f}  {r[:, 3].sum()/t*100:6.2f}  {r[:, 4].sum()/t*100:6.2f}  {r[:, 5].sum()/t*100:6.2f}  {r[:, 8].sum()/t*100:6.2f}  {r[:, 0].sum()/t*100:6.2f}")
+tot14 = buf.reshape(-1, 16).astype(np.float64)
+tot14 = tot14[tot14[:, :14].sum(1) > 0][:, 14]
+print(f"whole-kernel shader clocks per wave: mean {tot14.mean():.4g}  min {tot14.min():.4g}  max {tot14.max():.4g}  -> max = {tot14.max()/clk/1e3:.3f} ms at the in-kernel clock")
+perwg = buf.reshape(-1, 8, 16).astype(np.float64)[:, 0, 14]
+perwg = perwg[perwg > 0]
+srt = np.sort(perwg)
+print("per-workgroup clocks (wave 0) percentiles 0/25/50/75/100:", [f"{np.percentile(srt, q):.4g}" for q in (0, 25, 50, 75, 100)])
