@@ -1188,9 +1188,8 @@ static int ensure_tile_flags(pmf_ctx *c) {
 // sequence) it touched tile ti iff its range, taken relative to the segment start, contains an index == ti mod tps_cs.
 __global__ void k_gy_reduce(const float *__restrict__ slabs, int64_t stride, int G, int64_t T, int64_t n_rp, int tps,
                             int n_ct, int n_cseg, int Kp, int64_t N, float *__restrict__ gY) {
-  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= (int64_t)Kp * N) return;
-  const int ct = (int)((e / Kp) >> 5);
+  // one workgroup per column tile: the set of contributing workgroups is the same for all its 32 x Kp elements
+  const int ct = blockIdx.x;
   int cs = ct / tps;
   if (cs > n_cseg - 1) cs = n_cseg - 1;
   const int tps_cs = cs == n_cseg - 1 ? n_ct - (n_cseg - 1) * tps : tps;
@@ -1204,17 +1203,25 @@ __global__ void k_gy_reduce(const float *__restrict__ slabs, int64_t stride, int
     return (int)g;
   };
   const int g_lo = owner(s0), g_hi = owner(s1 - 1);
-  float acc = 0.f;
-  for (int g = g_lo; g <= g_hi; ++g) {
-    int64_t lo = (int64_t)g * T / G, hi = (int64_t)(g + 1) * T / G;
-    if (lo < s0) lo = s0;
-    if (hi > s1) hi = s1;
-    if (hi <= lo) continue;
-    const int64_t first = (lo - s0) % tps_cs;
-    const int64_t d = (ti - first + tps_cs) % tps_cs;
-    if (d < hi - lo) acc += slabs[(int64_t)g * stride + e];
+  const int64_t e0 = (int64_t)ct * 32 * Kp;
+  const int64_t rem = (int64_t)Kp * N - e0;
+  const int nel = rem > 32 * Kp ? 32 * Kp : (int)rem;
+  for (int q = threadIdx.x * 4; q < nel; q += blockDim.x * 4) {    // nel is a multiple of Kp, Kp of 32
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int g = g_lo; g <= g_hi; ++g) {
+      int64_t lo = (int64_t)g * T / G, hi = (int64_t)(g + 1) * T / G;
+      if (lo < s0) lo = s0;
+      if (hi > s1) hi = s1;
+      if (hi <= lo) continue;
+      const int64_t first = (lo - s0) % tps_cs;
+      const int64_t d = (ti - first + tps_cs) % tps_cs;
+      if (d < hi - lo) {
+        const float4 v = *reinterpret_cast<const float4 *>(slabs + (int64_t)g * stride + e0 + q);
+        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+      }
+    }
+    *reinterpret_cast<float4 *>(gY + e0 + q) = acc;
   }
-  gY[e] = acc;
 }
 
 template <int KB, int NW>
@@ -1336,8 +1343,7 @@ static int launch_fused(pmf_ctx *c, bool want_gx, bool want_gy) {
   PMFCHK(rc);
   HIPCHK(hipEventRecord(ev.second, c->stream));   // the events bracket pmf_fused_kernel alone (= rocprofv3's kernel duration)
   if (want_gy && !(a.dbg & 8)) {
-    const int64_t ne = slab_stride;
-    k_gy_reduce<<<(unsigned)((ne + 255) / 256), 256, 0, c->stream>>>(c->gy_slabs, slab_stride, grid, n_tiles, n_rp, a.tps, a.n_ct,
+    k_gy_reduce<<<(unsigned)a.n_ct, 256, 0, c->stream>>>(c->gy_slabs, slab_stride, grid, n_tiles, n_rp, a.tps, a.n_ct,
                                                                     a.n_cseg, c->Kp, c->N, c->P[1].g);
     HIPCHK(hipGetLastError());
   }
