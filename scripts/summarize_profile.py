@@ -10,7 +10,8 @@ tag = sys.argv[1]
 src = Path("gpurun_out") / f"prof_{tag}"
 dst = Path("profiles")
 dst.mkdir(exist_ok=True)
-stats = glob.glob(str(src / "stats" / "*" / "*_kernel_stats.csv"))[0]
+import os
+stats = max(glob.glob(str(src / "stats" / "*" / "*_kernel_stats.csv")), key=os.path.getmtime)   # newest run
 shutil.copy(stats, dst / f"{tag}_kernel_stats.csv")
 lines = [f"# rocprofv3 summary `{tag}` (python bench.py, 200000x50000 f32, K=64, 1 x MI355X)\n",
          "## kernel-trace --stats (top kernels)\n", "| kernel | calls | avg ms | % |", "|---|---|---|---|"]
@@ -24,7 +25,7 @@ for sub in ("pmc_sq", "pmc_fetch", "pmc_write"):
     if not fs:
         continue
     agg = collections.defaultdict(list)
-    for r in csv.DictReader(open(fs[0])):
+    for r in csv.DictReader(open(max(fs, key=os.path.getmtime))):
         if "pmf_fused_kernel" in r["Kernel_Name"]:
             agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
     for k, v in agg.items():
