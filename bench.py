@@ -5,7 +5,8 @@ Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N > 1 it
 torch.distributed.run with one rank per GPU.  Rank 0 prints ONE JSON line.
 
 Workload (BASELINE.json metric): synthetic 200000 x 50000 fp32 data matrix, K = 64, Gaussian loss, group
-regularizer on X (32 sample-condition groups), feature-set-ARD regularizer on Y, AdaGrad -- one "step" is one
+regularizer on X (32 sample-condition groups), feature-set-ARD regularizer on Y, Adam (north-star; --optimizer adagrad
+selects the reference's AdaGrad, same cost) -- one "step" is one
 fit! epoch: fused data pass over every local row (forward, masked loss, both gradient GEMMs), regularizer
 gradients, optimizer steps of X and Y, deterministic loss reduction.  The rows are sharded over the N GPUs
 (strong scaling: total work fixed), grad(Y) is all-reduced with RCCL and overlapped with the local X step.
@@ -26,7 +27,7 @@ sys.path.insert(0, str(ROOT))
 F32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense, = f32 vector peak
 
 
-def cpu_baseline(N, K, rows, epochs, seed):
+def cpu_baseline(N, K, rows, epochs, seed, opt, lr):
     """Times the CPU oracle (oracle/pmf_oracle.c, float build = the CPU *port* of the reference algorithm) on a
     bounded row sample of the same workload, all host cores via OpenMP.  Reported, not a target."""
     from oracle import pmf_oracle as po
@@ -43,9 +44,9 @@ def cpu_baseline(N, K, rows, epochs, seed):
                                   w=np.ones((ngr, K), np.float32))],
                        yreg=[dict(kind="fsard", alpha=np.full(N, 1.001, np.float32),
                                   beta=np.full((K, N), 0.001, np.float32))], precision=32)
-    m.fit(update_X=True, update_Y=True, lr=0.05, max_epochs=1, abs_tol=0, rel_tol=0)   # warm
+    m.fit(update_X=True, update_Y=True, opt=opt, lr=lr, max_epochs=1, abs_tol=0, rel_tol=0)   # warm
     t0 = time.time()
-    m.fit(update_X=True, update_Y=True, lr=0.05, max_epochs=1 + epochs, epoch=2, abs_tol=0, rel_tol=0)
+    m.fit(update_X=True, update_Y=True, opt=opt, lr=lr, max_epochs=1 + epochs, epoch=2, abs_tol=0, rel_tol=0)
     return (time.time() - t0) / epochs
 
 
@@ -57,6 +58,8 @@ def main():
     ap.add_argument("--M", type=int, default=int(os.environ.get("PMF_BENCH_M", 200000)))
     ap.add_argument("--N", type=int, default=int(os.environ.get("PMF_BENCH_N", 50000)))
     ap.add_argument("--K", type=int, default=int(os.environ.get("PMF_BENCH_K", 64)))
+    ap.add_argument("--optimizer", default=os.environ.get("PMF_BENCH_OPT", "adam"), choices=["adam", "adagrad"],
+                    help="adam = the north-star step; adagrad = the reference's construct_optimizer (src/fit.jl:41-43)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -109,7 +112,8 @@ def main():
     beta = (0.001 * (0.8 + 2.0 * rng_y.random((K, N)) * (rng_y.random((K, N)) < 0.05))).astype(np.float32)
     ctx.clear_yreg()
     ctx.add_yreg_fsard(np.full(N, 1.001, np.float32), beta)
-    ctx.set_optimizer("adagrad", lr=0.05)
+    lr = 0.05 if args.optimizer == "adagrad" else 0.01
+    ctx.set_optimizer(args.optimizer, lr=lr)
     o = ctx.make_opts(update_X=True, update_Y=True)
     use_dist = world > 1 or force_dist
     gY = parallel.grad_tensor(ctx, "Y") if use_dist else None
@@ -156,8 +160,8 @@ def main():
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": f"fit! epoch on synthetic {M}x{N} f32 matrix, K={K}, Gaussian loss, "
-                                   f"group-reg X (32 groups) + featureset-ARD Y, AdaGrad; rows sharded over {world} GPU(s)",
-                       "M": M, "N": N, "K": K, "rows_per_gpu": Ml, "optimizer": "adagrad",
+                                   f"group-reg X (32 groups) + featureset-ARD Y, {args.optimizer}; rows sharded over {world} GPU(s)",
+                       "M": M, "N": N, "K": K, "rows_per_gpu": Ml, "optimizer": args.optimizer, "lr": lr,
                        "parallelism": f"row-shard x{world}, RCCL all-reduce grad(Y)" if world > 1 else "single GPU"},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / F32_MFMA_PEAK_TFLOPS, "traffic": None,
@@ -177,7 +181,7 @@ def main():
             pass
         if world == 1 and not args.no_cpu_baseline:
             rows, ep = 3000, 3
-            t_epoch = cpu_baseline(N, K, rows, ep, seed)
+            t_epoch = cpu_baseline(N, K, rows, ep, seed, args.optimizer, lr)
             from oracle import pmf_oracle as po
             ncores = int(po.get_lib(32).lib.o_num_threads())     # OpenMP threads the oracle actually used
             out["cpu_baseline"] = {"value": 1.0 / (t_epoch * M / rows), "unit": "iters/s", "cores": ncores,
