@@ -90,6 +90,11 @@ struct pmf_ctx {
   bool state_init = false;
   // loss plumbing
   double *loss_partial = nullptr;
+  std::vector<uint8_t> h_kind;    // host copy of the per-column noise kind (cost model of the work split)
+  int64_t *wg_begin = nullptr;    // [grid + 1] device: first work item of each workgroup (fused kernel)
+  std::vector<int64_t> h_wg_begin;
+  int64_t wgb_key[8] = {-1, -1, -1, -1, -1, -1, -1, -1};   // geometry the cached split was computed for
+  int64_t kind_version = 0;
   float *gy_slabs = nullptr;      // [grid][Kp x N] private per-workgroup gY partial sums of the fused kernel
   size_t gy_slabs_cap = 0;        // floats
   int64_t loss_cap = 0;
@@ -669,7 +674,7 @@ extern "C" int pmf_destroy(pmf_ctx *c) {
   dev_free(&c->bor); dev_free(&c->btab); dev_free(&c->d_val_view);
   dev_free(&c->colmeta); dev_free(&c->colw); dev_free(&c->colp);
   dev_free(&c->ard_alpha); dev_free(&c->ard_beta);
-  dev_free(&c->gy_slabs); dev_free(&c->loss_partial); dev_free(&c->reg_partial); dev_free(&c->d_loss);
+  dev_free(&c->wg_begin); dev_free(&c->gy_slabs); dev_free(&c->loss_partial); dev_free(&c->reg_partial); dev_free(&c->d_loss);
   if (c->h_loss) (void)hipHostFree(c->h_loss);
   if (c->scratch) (void)hipFree(c->scratch);
   for (auto &e : c->ev_pool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
@@ -944,6 +949,8 @@ extern "C" int pmf_set_noise(pmf_ctx *c, int n_ranges, const int64_t *s1, const 
   HIPCHK(hipMemcpy(c->colmeta, meta.data(), sizeof(int32_t) * (size_t)c->N, hipMemcpyHostToDevice));
   if (weights) HIPCHK(hipMemcpy(c->colw, weights, sizeof(float) * (size_t)c->N, hipMemcpyHostToDevice));
   c->mixed = mixed;
+  c->h_kind.assign(meta.begin(), meta.end());
+  c->kind_version++;
   PMFCHK(rebuild_colmeta_views(c));
   return 0;
 }
@@ -1186,8 +1193,8 @@ static int ensure_tile_flags(pmf_ctx *c) {
 // order: grad(Y) is bitwise reproducible).  The work sequence (pmf_fused_kernel) is segment-major, then row panel,
 // then tile; workgroup g owns [g*T/G, (g+1)*T/G).  Inside segment cs (tiles [cs*S, cs*S + n_rp*tps_cs) of the
 // sequence) it touched tile ti iff its range, taken relative to the segment start, contains an index == ti mod tps_cs.
-__global__ void k_gy_reduce(const float *__restrict__ slabs, int64_t stride, int G, int64_t T, int64_t n_rp, int tps,
-                            int n_ct, int n_cseg, int Kp, int64_t N, float *__restrict__ gY) {
+__global__ void k_gy_reduce(const float *__restrict__ slabs, int64_t stride, int G, const int64_t *__restrict__ wgb,
+                            int64_t n_rp, int tps, int n_ct, int n_cseg, int Kp, int64_t N, float *__restrict__ gY) {
   // one workgroup per column tile: the set of contributing workgroups is the same for all its 32 x Kp elements
   const int ct = blockIdx.x;
   int cs = ct / tps;
@@ -1195,12 +1202,13 @@ __global__ void k_gy_reduce(const float *__restrict__ slabs, int64_t stride, int
   const int tps_cs = cs == n_cseg - 1 ? n_ct - (n_cseg - 1) * tps : tps;
   const int ti = ct - cs * tps;
   const int64_t s0 = (int64_t)cs * n_rp * tps, s1 = s0 + n_rp * tps_cs;   // the segment's slice of the sequence
-  auto owner = [&](int64_t u) {
-    int64_t g = (u * G) / T;
-    if (g > G - 1) g = G - 1;
-    while (g + 1 < G && (g + 1) * T / G <= u) ++g;
-    while (g > 0 && g * T / G > u) --g;
-    return (int)g;
+  auto owner = [&](int64_t u) {   // last g with wgb[g] <= u
+    int lo = 0, hi = G - 1;
+    while (lo < hi) {
+      const int mid = (lo + hi + 1) >> 1;
+      if (wgb[mid] <= u) lo = mid; else hi = mid - 1;
+    }
+    return lo;
   };
   const int g_lo = owner(s0), g_hi = owner(s1 - 1);
   const int64_t e0 = (int64_t)ct * 32 * Kp;
@@ -1209,7 +1217,7 @@ __global__ void k_gy_reduce(const float *__restrict__ slabs, int64_t stride, int
   for (int q = threadIdx.x * 4; q < nel; q += blockDim.x * 4) {    // nel is a multiple of Kp, Kp of 32
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int g = g_lo; g <= g_hi; ++g) {
-      int64_t lo = (int64_t)g * T / G, hi = (int64_t)(g + 1) * T / G;
+      int64_t lo = wgb[g], hi = wgb[g + 1];
       if (lo < s0) lo = s0;
       if (hi > s1) hi = s1;
       if (hi <= lo) continue;
@@ -1222,6 +1230,56 @@ __global__ void k_gy_reduce(const float *__restrict__ slabs, int64_t stride, int
     }
     *reinterpret_cast<float4 *>(gY + e0 + q) = acc;
   }
+}
+
+// Cost-balanced split of the fused kernel's work sequence (segment-major, row panel, tile) into `grid` contiguous
+// ranges.  A tile's estimated cost depends on the noise models of its 32 columns (measured on MI355X: a Bernoulli
+// tile costs 1.4x a Gaussian one, Poisson 1.3x); with Gaussian-only data this is the even split g*T/G.
+static int compute_work_split(pmf_ctx *c, int grid, int64_t n_rp, int64_t n_ct, int64_t tps, int64_t n_cseg) {
+  const int64_t key[8] = {c->M, c->N, c->Kp, grid, n_rp, tps, n_cseg, c->kind_version};
+  if (c->wg_begin && memcmp(key, c->wgb_key, sizeof(key)) == 0) return 0;
+  std::vector<int64_t> tw((size_t)n_ct, 16);
+  if (c->mixed && (int64_t)c->h_kind.size() == c->N) {
+    for (int64_t ct = 0; ct < n_ct; ++ct) {
+      int64_t wmax = 16;
+      for (int64_t j = ct * 32; j < std::min<int64_t>(c->N, ct * 32 + 32); ++j) {
+        const int k = c->h_kind[(size_t)j];
+        wmax = std::max<int64_t>(wmax, k == PMF_NOISE_BERNOULLI ? 22 : (k == PMF_NOISE_POISSON ? 21 : 16));
+      }
+      tw[(size_t)ct] = wmax;
+    }
+  }
+  // per segment: first tile, tile count, weight of one row panel's sweep
+  std::vector<int64_t> seg_t0((size_t)n_cseg), seg_nt((size_t)n_cseg), seg_w((size_t)n_cseg), seg_pref((size_t)n_cseg + 1, 0);
+  for (int64_t cs = 0; cs < n_cseg; ++cs) {
+    seg_t0[(size_t)cs] = cs * tps;
+    seg_nt[(size_t)cs] = cs == n_cseg - 1 ? n_ct - cs * tps : tps;
+    int64_t w = 0;
+    for (int64_t t = 0; t < seg_nt[(size_t)cs]; ++t) w += tw[(size_t)(seg_t0[(size_t)cs] + t)];
+    seg_w[(size_t)cs] = w;
+    seg_pref[(size_t)cs + 1] = seg_pref[(size_t)cs] + w * n_rp;
+  }
+  const int64_t W = seg_pref[(size_t)n_cseg], T = n_rp * n_ct;
+  c->h_wg_begin.assign((size_t)grid + 1, 0);
+  for (int g = 1; g < grid; ++g) {
+    const int64_t target = (int64_t)((__int128)W * g / grid);
+    int64_t cs = 0;
+    while (cs + 1 < n_cseg && seg_pref[(size_t)cs + 1] <= target) ++cs;
+    int64_t rem = target - seg_pref[(size_t)cs];
+    const int64_t rp = std::min<int64_t>(n_rp - 1, rem / seg_w[(size_t)cs]);
+    rem -= rp * seg_w[(size_t)cs];
+    int64_t ti = 0;
+    while (ti + 1 < seg_nt[(size_t)cs] && rem >= tw[(size_t)(seg_t0[(size_t)cs] + ti)]) { rem -= tw[(size_t)(seg_t0[(size_t)cs] + ti)]; ++ti; }
+    int64_t idx = cs * n_rp * tps + rp * seg_nt[(size_t)cs] + ti;
+    idx = std::max(idx, c->h_wg_begin[(size_t)g - 1]);      // monotone
+    c->h_wg_begin[(size_t)g] = std::min(idx, T);
+  }
+  c->h_wg_begin[(size_t)grid] = T;
+  PMFCHK(dev_alloc(&c->wg_begin, (size_t)grid + 1, false));
+  HIPCHK(hipMemcpyAsync(c->wg_begin, c->h_wg_begin.data(), sizeof(int64_t) * ((size_t)grid + 1), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));   // h_wg_begin is pageable host memory
+  memcpy(c->wgb_key, key, sizeof(key));
+  return 0;
 }
 
 template <int KB, int NW>
@@ -1295,9 +1353,11 @@ static int launch_fused(pmf_ctx *c, bool want_gx, bool want_gy) {
     c->gy_slabs_cap = (size_t)grid * (size_t)slab_stride;
   }
   PMFCHK(ensure_tile_flags(c));
+  PMFCHK(compute_work_split(c, grid, n_rp, n_ct, tiles_per_seg, n_cseg));
   FusedArgs a;
   memset(&a, 0, sizeof(a));
   a.tflags = c->tflags;
+  a.wg_begin = c->wg_begin;
   a.D = c->D; a.X = c->P[0].p; a.Y = c->P[1].p; a.gX = c->P[0].g; a.gY = c->P[1].g;
   a.colp = c->colp; a.bor = c->bor; a.btab = c->btab; a.loss_partial = c->loss_partial;
   a.nRB = c->nRB; a.gy_slabs = c->gy_slabs; a.slab_stride = slab_stride; a.n_rp = n_rp;
@@ -1343,7 +1403,7 @@ static int launch_fused(pmf_ctx *c, bool want_gx, bool want_gy) {
   PMFCHK(rc);
   HIPCHK(hipEventRecord(ev.second, c->stream));   // the events bracket pmf_fused_kernel alone (= rocprofv3's kernel duration)
   if (want_gy && !(a.dbg & 8)) {
-    k_gy_reduce<<<(unsigned)a.n_ct, 256, 0, c->stream>>>(c->gy_slabs, slab_stride, grid, n_tiles, n_rp, a.tps, a.n_ct,
+    k_gy_reduce<<<(unsigned)a.n_ct, 256, 0, c->stream>>>(c->gy_slabs, slab_stride, grid, c->wg_begin, n_rp, a.tps, a.n_ct,
                                                                     a.n_cseg, c->Kp, c->N, c->P[1].g);
     HIPCHK(hipGetLastError());
   }
