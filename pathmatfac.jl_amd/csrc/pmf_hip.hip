@@ -73,6 +73,10 @@ struct pmf_ctx {
   std::vector<int64_t> bvb_off;  // per view offset into the flat per-(view,batch) arrays
   int32_t *bor = nullptr;
   float2 *btab = nullptr;
+  ViewDesc *d_views = nullptr;    // device copy of `views` for the fused kernel's global-gather fallback
+  float2 *btd = nullptr;          // dense per-column batch table [ceil(N/32)*32][16] (fused kernel, LDS path); see k_dense_btab
+  int64_t btd_cap = 0;
+  bool btd_ok = false;            // every view has <= 15 batches: the dense table is usable
   int32_t *d_val_view = nullptr;  // per flat value element: view id
   // noise model / prepared column parameters
   int32_t *colmeta = nullptr;  // kind | (view+1)<<2
@@ -176,6 +180,30 @@ __global__ void k_prepare(const float *logsigma, const float *mu, const float *c
   const int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   if (e < N) colp[e] = make_float4(expf(logsigma[e]), mu[e], colw[e], __int_as_float(colmeta[e]));
   if (e < nbt) btab[e] = make_float2(expf(logdelta[e]), theta[e]);
+}
+
+// Dense form of the batch tables for the fused kernel: btd[j*16 + b] = {exp(logdelta), theta} of (column j's view,
+// batch b), identity {1, 0} for b >= the view's batch count (slot 15 is always identity: rows outside every batch),
+// for columns outside every view and for the pad columns up to the next multiple of 32.  A tile's 32 columns are then
+// one contiguous 4-KiB read, staged in LDS, and the epilogue needs no view arithmetic.
+struct DenseBtabArgs {
+  const int32_t *colmeta;
+  const float2 *btab;
+  float2 *btd;
+  int64_t N, Npad;
+  ViewDesc views[PMF_MAXV];
+};
+__global__ void k_dense_btab(const DenseBtabArgs a) {
+  const int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (e >= a.Npad * 16) return;
+  const int64_t j = e >> 4;
+  const int b = (int)(e & 15);
+  float2 out = make_float2(1.f, 0.f);
+  if (j < a.N) {
+    const int v = (a.colmeta[j] >> 2) - 1;
+    if (v >= 0 && b < a.views[v].nb && b < 15) out = a.btab[a.views[v].tab_off + (j - a.views[v].c0) * a.views[v].nb + b];
+  }
+  a.btd[e] = out;
 }
 
 // dense quadratic weights from ranges: wq[k, i] += p * w[g, k] for i in range g   (GroupRegularizer / L2Regularizer)
@@ -671,7 +699,7 @@ extern "C" int pmf_destroy(pmf_ctx *c) {
   for (auto &b : c->P) param_free(b);
   if (c->own_D) dev_free(&c->D);
   dev_free(&c->tflags);
-  dev_free(&c->bor); dev_free(&c->btab); dev_free(&c->d_val_view);
+  dev_free(&c->bor); dev_free(&c->btab); dev_free(&c->btd); c->btd_cap = 0; c->btd_ok = false; dev_free(&c->d_views); dev_free(&c->d_val_view);
   dev_free(&c->colmeta); dev_free(&c->colw); dev_free(&c->colp);
   dev_free(&c->ard_alpha); dev_free(&c->ard_beta);
   dev_free(&c->wg_begin); dev_free(&c->gy_slabs); dev_free(&c->loss_partial); dev_free(&c->reg_partial); dev_free(&c->d_loss);
@@ -717,7 +745,7 @@ static int data_shape_changed(pmf_ctx *c, int64_t M, int64_t N) {
   c->views.clear();
   c->val_off.clear();
   c->bvb_off.clear();
-  dev_free(&c->bor); dev_free(&c->btab); dev_free(&c->d_val_view);
+  dev_free(&c->bor); dev_free(&c->btab); dev_free(&c->btd); c->btd_cap = 0; c->btd_ok = false; dev_free(&c->d_views); dev_free(&c->d_val_view);
   PMFCHK(dev_alloc(&c->colmeta, (size_t)N));
   PMFCHK(dev_alloc(&c->colw, (size_t)N));
   PMFCHK(dev_alloc(&c->colp, (size_t)N));
@@ -1159,6 +1187,28 @@ static int prepare(pmf_ctx *c) {
   k_prepare<<<nblocks(n, 256), 256, 0, c->stream>>>(c->P[2].p, c->P[3].p, c->colw, c->colmeta, c->colp, c->N,
                                                     c->P[4].p, c->P[5].p, c->btab, nbt);
   HIPCHK(hipGetLastError());
+  c->btd_ok = false;
+  if (c->n_bv > 0) {
+    PMFCHK(dev_alloc(&c->d_views, (size_t)PMF_MAXV, false));
+    HIPCHK(hipMemcpyAsync(c->d_views, c->views.data(), sizeof(ViewDesc) * (size_t)c->n_bv, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    int nb_max = 0;
+    for (int v = 0; v < c->n_bv; ++v) nb_max = std::max(nb_max, (int)c->views[v].nb);
+    if (nb_max <= 15) {
+      const int64_t Npad = (c->N + 31) / 32 * 32;
+      if (Npad * 16 > c->btd_cap) {
+        PMFCHK(dev_alloc(&c->btd, (size_t)(Npad * 16), false));
+        c->btd_cap = Npad * 16;
+      }
+      DenseBtabArgs da;
+      memset(&da, 0, sizeof(da));
+      da.colmeta = c->colmeta; da.btab = c->btab; da.btd = c->btd; da.N = c->N; da.Npad = Npad;
+      for (int v = 0; v < c->n_bv; ++v) da.views[v] = c->views[v];
+      k_dense_btab<<<nblocks(Npad * 16, 256), 256, 0, c->stream>>>(da);
+      HIPCHK(hipGetLastError());
+      c->btd_ok = true;
+    }
+  }
   c->prepared = true;
   return 0;
 }
@@ -1284,18 +1334,23 @@ static int compute_work_split(pmf_ctx *c, int grid, int64_t n_rp, int64_t n_ct, 
 
 template <int KB, int NW>
 static int launch_fused_t(pmf_ctx *c, const FusedArgs &a, int grid, bool batch, bool mixed) {
-  const size_t lds = pmf_fused_lds_bytes<KB, NW>();
+  const size_t lds = pmf_fused_lds_bytes<KB, NW>() + (batch ? FusedCfg<KB, NW>::lds_batch_extra : 0);
   const bool full = a.want_gx && a.want_gy && a.dbg == 0;
   void (*kern)(const FusedArgs) = nullptr;
+  const int bmode = !batch ? 0 : (a.btd ? 1 : 2);
+#define PMF_PICK(BM, MX, FU) pmf_fused_kernel<KB, NW, BM, MX, FU>
   if (full) {
-    if (batch) kern = mixed ? pmf_fused_kernel<KB, NW, true, true, true> : pmf_fused_kernel<KB, NW, true, false, true>;
-    else kern = mixed ? pmf_fused_kernel<KB, NW, false, true, true> : pmf_fused_kernel<KB, NW, false, false, true>;
+    if (bmode == 0) kern = mixed ? PMF_PICK(0, true, true) : PMF_PICK(0, false, true);
+    else if (bmode == 1) kern = mixed ? PMF_PICK(1, true, true) : PMF_PICK(1, false, true);
+    else kern = mixed ? PMF_PICK(2, true, true) : PMF_PICK(2, false, true);
   } else {
-    if (batch) kern = mixed ? pmf_fused_kernel<KB, NW, true, true, false> : pmf_fused_kernel<KB, NW, true, false, false>;
-    else kern = mixed ? pmf_fused_kernel<KB, NW, false, true, false> : pmf_fused_kernel<KB, NW, false, false, false>;
+    if (bmode == 0) kern = mixed ? PMF_PICK(0, true, false) : PMF_PICK(0, false, false);
+    else if (bmode == 1) kern = mixed ? PMF_PICK(1, true, false) : PMF_PICK(1, false, false);
+    else kern = mixed ? PMF_PICK(2, true, false) : PMF_PICK(2, false, false);
   }
-  static bool attr_set[8] = {false, false, false, false, false, false, false, false};
-  const int vi = (full ? 4 : 0) + (batch ? 2 : 0) + (mixed ? 1 : 0);
+#undef PMF_PICK
+  static bool attr_set[12] = {false, false, false, false, false, false, false, false, false, false, false, false};
+  const int vi = (full ? 6 : 0) + bmode * 2 + (mixed ? 1 : 0);
   if (!attr_set[vi]) {
     HIPCHK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_set[vi] = true;
@@ -1360,6 +1415,7 @@ static int launch_fused(pmf_ctx *c, bool want_gx, bool want_gy) {
   a.wg_begin = c->wg_begin;
   a.D = c->D; a.X = c->P[0].p; a.Y = c->P[1].p; a.gX = c->P[0].g; a.gY = c->P[1].g;
   a.colp = c->colp; a.bor = c->bor; a.btab = c->btab; a.loss_partial = c->loss_partial;
+  a.btd = (c->n_bv > 0 && c->btd_ok) ? c->btd : nullptr; a.n_bv = c->n_bv;
   a.nRB = c->nRB; a.gy_slabs = c->gy_slabs; a.slab_stride = slab_stride; a.n_rp = n_rp;
   a.M = c->M; a.N = c->N; a.n_tiles = n_tiles; a.tps = (int)tiles_per_seg; a.n_ct = (int)n_ct; a.n_cseg = (int)n_cseg;
   a.want_gx = want_gx; a.want_gy = want_gy;
@@ -1376,7 +1432,7 @@ static int launch_fused(pmf_ctx *c, bool want_gx, bool want_gy) {
     g_stamps = d_stamps;
   }
 #endif
-  for (int v = 0; v < c->n_bv; ++v) a.views[v] = c->views[v];
+  a.views = c->d_views;
   const bool batch = c->n_bv > 0;
   // timing events
   if (c->ev_used == c->ev_pool.size()) {

@@ -85,6 +85,9 @@ CASES = {
                             nan_frac=0.1, weights=True, col_params=True, xreg="composite", yreg="fsard"),
     "poisson_batch": dict(M=150, N=90, K=8, poisson_frac=0.3, bernoulli_frac=0.2, n_views=3, batch_views=2,
                           weights=True, col_params=True, scale=0.4),
+    # more than 15 batches in a view: the fused kernel falls back from the LDS-staged dense batch table to global gathers
+    "batch_20_batches": dict(M=300, N=100, K=16, n_views=2, batch_views=2, n_batches=20, nan_frac=0.05, weights=True,
+                             col_params=True, bernoulli_frac=0.3),
     "tiny": dict(M=5, N=7, K=2),
     "one_row_panel_many_cols": dict(M=33, N=1500, K=16, nan_frac=0.02),
     # more work units than workgroups: a workgroup visits several row panels of one column segment (its private gY
