@@ -1525,7 +1525,8 @@ static int step_param(pmf_ctx *c, int which, bool do_step, bool use_reg, int reg
   s.opt_kind = c->opt_kind; s.lr = c->lr; s.eps = c->eps; s.b1 = c->b1; s.b2 = c->b2;
   s.c1 = 1.f - b.bp1; s.c2 = 1.f - b.bp2;
   s.do_step = do_step; s.use_reg = use_reg;
-  const int grid = (int)std::min<int64_t>(REG_SLOTS, nblocks(b.n, 256));
+  // the four layer parameters share one slab of loss partials: each gets a quarter (k_reg_step is grid-stride)
+  const int grid = (int)std::min<int64_t>(reg_slot == 2 ? REG_SLOTS / 4 : REG_SLOTS, nblocks(b.n, 256));
   s.reg_partial = c->reg_partial + (int64_t)reg_slot * REG_SLOTS + *reg_count;
   if (*reg_count + grid > REG_SLOTS) return pmf_fail("internal: regularizer partial slab overflow");
   k_reg_step<<<grid, 256, 0, c->stream>>>(s);
