@@ -384,10 +384,17 @@ struct LayerGradArgs {
   int64_t val_off[PMF_MAXV];
 };
 
+// One wave per workgroup: thread = column (64 consecutive columns), sequential over a chunk of rows.  The column of Y
+// lives in registers (32*KB floats), four rows of X at a time are staged in LDS and read back as broadcast 16-B reads
+// (a single wave needs no barrier: LDS operations of one wave complete in order), per-(batch, column) sums in LDS
+// (no contention), one atomic per (batch, column) per workgroup at the end.
+template <int KB>
 __global__ __launch_bounds__(64) void k_layer_grad(const LayerGradArgs a) {
+  constexpr int Kp = 32 * KB;
+  constexpr int RG = 4;   // rows per group
   extern __shared__ __attribute__((aligned(16))) char smem_lg[];
-  float *xs = reinterpret_cast<float *>(smem_lg);  // [Kp] current row of X (broadcast)
-  float *bacc = xs + a.Kp;                         // [2][max_nb][64] per-(batch,column) sums
+  float *xs = reinterpret_cast<float *>(smem_lg);  // [RG][Kp] current rows of X (broadcast)
+  float *bacc = xs + RG * Kp;                      // [2][max_nb][64] per-(batch,column) sums
   __shared__ double sh[4];
   const int tid = threadIdx.x;
   const int64_t j = blockIdx.x * 64 + tid;
@@ -404,51 +411,75 @@ __global__ __launch_bounds__(64) void k_layer_grad(const LayerGradArgs a) {
   for (int e = tid; e < 2 * a.max_nb * 64; e += 64) bacc[e] = 0.f;
   float smu = 0.f, sls = 0.f;
   double lacc = 0.0;
-  const float *y = a.Y + jc * a.Kp;
-  for (int64_t i = r0; i < r1; ++i) {
-    __syncthreads();
-    for (int k = tid; k < a.Kp; k += 64) xs[k] = a.X[i * a.Kp + k];
-    __syncthreads();
-    float acc = 0.f;
-    for (int k = 0; k < a.K; ++k) acc = fmaf(xs[k], y[k], acc);
-    float dl = 1.f, th = 0.f;
-    int b = -1;
-    if (v >= 0) {
-      b = a.bor[(int64_t)v * a.M + i];
-      if (b >= 0) {
-        const float2 dt = a.btab[vd.tab_off + (jc - vd.c0) * vd.nb + b];
-        dl = dt.x;
-        th = dt.y;
+  float4 yr[Kp / 4];
+  {
+    const float4 *y4 = reinterpret_cast<const float4 *>(a.Y + jc * Kp);
+#pragma unroll
+    for (int q = 0; q < Kp / 4; ++q) yr[q] = y4[q];
+  }
+  for (int64_t ib = r0; ib < r1; ib += RG) {
+    // stage RG rows of X (contiguous in memory: X is Kp x M column-major); rows past the chunk are clamped
+    __builtin_amdgcn_wave_barrier();
+    for (int e4 = tid; e4 < RG * Kp / 4; e4 += 64) {
+      const int rr = (e4 * 4) / Kp;
+      const int64_t i = ib + rr < r1 ? ib + rr : r1 - 1;
+      reinterpret_cast<float4 *>(xs)[e4] = reinterpret_cast<const float4 *>(a.X + i * Kp)[(e4 * 4 % Kp) / 4];
+    }
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int rr = 0; rr < RG; ++rr) {
+      const int64_t i = ib + rr;
+      if (i >= r1) break;
+      const float4 *x4 = reinterpret_cast<const float4 *>(xs + rr * Kp);
+      float acc0 = 0.f, acc1 = 0.f;
+#pragma unroll
+      for (int q = 0; q < Kp / 4; ++q) {
+        const float4 xv = x4[q];
+        acc0 = fmaf(xv.x, yr[q].x, acc0);
+        acc1 = fmaf(xv.y, yr[q].y, acc1);
+        acc0 = fmaf(xv.z, yr[q].z, acc0);
+        acc1 = fmaf(xv.w, yr[q].w, acc1);
       }
-    }
-    const float yv = a.D[pmf_d_off(i, jc, a.nRB)];
-    const float z1 = acc * cp.x;
-    const float z = fmaf(z1, dl, cp.y + th);
-    float l, g;
-    if (kind == PMF_NOISE_NORMAL) {
-      const float d = z - yv;
-      g = cp.z * d;
-      l = 0.5f * g * d;
-    } else if (kind == PMF_NOISE_BERNOULLI) {
-      const float e = __expf(-fabsf(z));
-      const float sp = fmaxf(z, 0.f) + __logf(1.f + e);
-      const float r = __frcp_rn(1.f + e);
-      const float sg = z >= 0.f ? r : e * r;
-      l = cp.z * (sp - yv * z);
-      g = cp.z * (sg - yv);
-    } else {
-      const float e = __expf(z);
-      l = cp.z * (e - yv * z);
-      g = cp.z * (e - yv);
-    }
-    const bool ok = (kind != 3) && (fabsf(yv) <= 3.402823466e38f);
-    if (!ok) { l = 0.f; g = 0.f; }
-    lacc += (double)l;
-    smu += g;
-    sls += g * dl;
-    if (b >= 0) {
-      bacc[b * 64 + tid] += g;
-      bacc[(a.max_nb + b) * 64 + tid] += g * z1;
+      const float acc = acc0 + acc1;
+      float dl = 1.f, th = 0.f;
+      int b = -1;
+      if (v >= 0) {
+        b = a.bor[(int64_t)v * a.M + i];
+        if (b >= 0) {
+          const float2 dt = a.btab[vd.tab_off + (jc - vd.c0) * vd.nb + b];
+          dl = dt.x;
+          th = dt.y;
+        }
+      }
+      const float yv = a.D[pmf_d_off(i, jc, a.nRB)];
+      const float z1 = acc * cp.x;
+      const float z = fmaf(z1, dl, cp.y + th);
+      float l, g;
+      if (kind == PMF_NOISE_NORMAL) {
+        const float d = z - yv;
+        g = cp.z * d;
+        l = 0.5f * g * d;
+      } else if (kind == PMF_NOISE_BERNOULLI) {
+        const float e = __expf(-fabsf(z));
+        const float sp = fmaxf(z, 0.f) + __logf(1.f + e);
+        const float r = __frcp_rn(1.f + e);
+        const float sg = z >= 0.f ? r : e * r;
+        l = cp.z * (sp - yv * z);
+        g = cp.z * (sg - yv);
+      } else {
+        const float e = __expf(z);
+        l = cp.z * (e - yv * z);
+        g = cp.z * (e - yv);
+      }
+      const bool ok = (kind != 3) && (fabsf(yv) <= 3.402823466e38f);
+      if (!ok) { l = 0.f; g = 0.f; }
+      lacc += (double)l;
+      smu += g;
+      sls += g * dl;
+      if (b >= 0) {
+        bacc[b * 64 + tid] += g;
+        bacc[(a.max_nb + b) * 64 + tid] += g * z1;
+      }
     }
   }
   if (col_ok) {
@@ -469,13 +500,6 @@ __global__ __launch_bounds__(64) void k_layer_grad(const LayerGradArgs a) {
   if (tid == 0 && a.loss_partial) a.loss_partial[(int64_t)blockIdx.y * gridDim.x + blockIdx.x] = s;
 }
 
-// ------------------------------------------------------------------------------------------------
-// Column / (batch, column) statistics for the closed-form initialisers between the GD stages:
-//   n_j = #finite D_ij, sum, sumsq            -> MF.column_nonnan, MF.batched_column_nanvar (regularizers.jl:765-766)
-//   sqerr_j = sum_i (invlink(z_ij) - D_ij)^2  -> MF.link_col_sqerr (fit.jl:138, 444)      [self-specified, DESIGN.md]
-//   ssqg_j = sum_i (dl/dz)^2                  -> MF.batched_column_ssq_grads (fit.jl:166)
-//   per (batch, column): count, sqerr         -> ba_map(isfinite) / ba_map(MF.sqerr_func) (fit.jl:332, 355, 454-456)
-// use_factors = 0 evaluates z with X'Y = 0 (the reference zeroes X and Y around these calls: fit.jl:133-136, 160-163).
 // Same thread-per-column structure as k_layer_grad; called a handful of times per fit, not per epoch.
 // ------------------------------------------------------------------------------------------------
 struct StatsArgs {
@@ -1484,7 +1508,9 @@ static int launch_layer_grad(pmf_ctx *c, const pmf_fit_opts *o, bool with_loss) 
   }
   a.max_nb = max_nb;
   const int gx = nblocks(c->N, 64);
-  int64_t gy = std::max<int64_t>(1, std::min<int64_t>((4ll * c->n_cu + gx - 1) / gx, (c->M + 63) / 64));
+  // ~32 single-wave workgroups per CU hide the FMA / LDS latencies; at least 256 rows per workgroup keep the final
+  // atomics (64 * (2 + 2 nb) per workgroup) negligible
+  int64_t gy = std::max<int64_t>(1, std::min<int64_t>((32ll * c->n_cu + gx - 1) / gx, (c->M + 255) / 256));
   a.rows_per_block = (int)((c->M + gy - 1) / gy);
   gy = (c->M + a.rows_per_block - 1) / a.rows_per_block;
   const int64_t nslots = (int64_t)gx * gy;
@@ -1496,10 +1522,18 @@ static int launch_layer_grad(pmf_ctx *c, const pmf_fit_opts *o, bool with_loss) 
     c->n_macro = nslots;
     a.loss_partial = c->loss_partial;
   }
-  const size_t lds = sizeof(float) * (size_t)(c->Kp + 2 * max_nb * 64);
+  const size_t lds = sizeof(float) * (size_t)(4 * c->Kp + 2 * max_nb * 64);
   if (lds > 160 * 1024) return pmf_fail("too many row batches per view (%d) for the layer-gradient kernel", max_nb);
-  HIPCHK(hipFuncSetAttribute((const void *)k_layer_grad, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL(k_layer_grad, dim3(gx, (unsigned)gy), dim3(64), lds, c->stream, a);
+  void (*kern)(const LayerGradArgs) = nullptr;
+  switch (c->KB) {
+    case 1: kern = k_layer_grad<1>; break;
+    case 2: kern = k_layer_grad<2>; break;
+    case 3: kern = k_layer_grad<3>; break;
+    case 4: kern = k_layer_grad<4>; break;
+    default: return pmf_fail("unsupported KB=%d", c->KB);
+  }
+  HIPCHK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(kern, dim3(gx, (unsigned)gy), dim3(64), lds, c->stream, a);
   HIPCHK(hipGetLastError());
   return 0;
 }
