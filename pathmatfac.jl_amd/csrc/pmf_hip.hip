@@ -1410,14 +1410,21 @@ static int launch_fused(pmf_ctx *c, bool want_gx, bool want_gy) {
   const int BM = 32 * NW;
   const int64_t n_rp = (c->M + BM - 1) / BM;
   const int64_t n_ct = (c->N + PMF_BN - 1) / PMF_BN;  // column tiles
-  // column segments: enough macro tiles to balance the CUs, but at least 8 tiles (512 columns) per segment
-  int64_t n_cseg = 1;
-  const int64_t target = 16ll * c->n_cu;
-  if (n_rp < target) n_cseg = std::min<int64_t>((target + n_rp - 1) / n_rp, std::max<int64_t>(1, n_ct / 8));
-  // equal segments of floor(n_ct / n_cseg) tiles; the LAST one takes the remainder (it is longer, never tiny: every
-  // piece of work pays a fixed prologue, so a 5-tile last segment made one workgroup 20 % late)
-  const int64_t tiles_per_seg = std::max<int64_t>(1, n_ct / n_cseg);
-  n_cseg = std::max<int64_t>(1, n_ct / tiles_per_seg);
+  // Column segments.  The work split is balanced to a tile whatever the segmentation, so the segment length only trades
+  //   (a) the fixed cost of a piece (X panel, first Y / D tile, gX flush: ~8 us) -- a workgroup walks
+  //       (T/G)/tps + 2 pieces -- against
+  //   (b) k_gy_reduce, which reads the private slabs of the ~G*tps/n_ct + 1 workgroups that visited a column tile
+  //       (Kp*N*4 bytes each at ~4 TB/s).
+  // tps* = sqrt(a/b) minimises a/tps + b*tps.
+  const int grid0 = (int)std::min<int64_t>(n_rp * n_ct, (int64_t)c->n_cu * ((NW == 4 && c->KB <= 2) ? 2 : 1));
+  const double tiles_per_wg = (double)(n_rp * n_ct) / grid0;
+  const double a_cost = tiles_per_wg * 8e-6;
+  const double b_cost = (double)grid0 * (double)c->Kp * (double)c->N * 4.0 / ((double)n_ct * 4e12);
+  int64_t tiles_per_seg = (int64_t)std::llround(std::sqrt(a_cost / std::max(b_cost, 1e-12)));
+  tiles_per_seg = std::max<int64_t>(std::min<int64_t>(8, n_ct), std::min<int64_t>(tiles_per_seg, n_ct));
+  // equal segments; the LAST one takes the remainder (it is longer, never tiny: every piece of work pays the fixed
+  // prologue, so a 5-tile last segment once made one workgroup 20 % late)
+  const int64_t n_cseg = std::max<int64_t>(1, n_ct / tiles_per_seg);
   const int64_t n_tiles = n_rp * n_ct;   // the kernel's work items, dealt out in contiguous, balanced ranges
   const int grid = (int)std::min<int64_t>(n_tiles, (int64_t)c->n_cu * ((NW == 4 && c->KB <= 2) ? 2 : 1));
   if (grid > c->loss_cap) {
