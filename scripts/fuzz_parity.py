@@ -1,0 +1,61 @@
+"""Randomised parity sweep: HIP path vs the fp64 oracle on random shapes / models (development aid, GPU box).
+python scripts/fuzz_parity.py [n_cases] [seed]"""
+import sys
+from pathlib import Path
+import numpy as np
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT)); sys.path.insert(0, str(ROOT / "tests"))
+import pmf_import
+pkg = pmf_import.load()
+from problems import make_problem, rel_err, to_context, to_oracle
+
+n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 60
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+ctx = pkg.Context(0)
+worst = dict(loss=0.0, gx=0.0, gy=0.0, layer=0.0)
+for c in range(n_cases):
+    K = int(rng.choice([1, 2, 4, 7, 16, 31, 32, 33, 64, 65, 96, 100, 128]))
+    M = int(rng.choice([1, 3, 31, 32, 33, 255, 256, 257, 600, 1500, 5000, 20000, 70000]))
+    N = int(rng.choice([1, 5, 31, 32, 33, 63, 64, 65, 200, 777, 2500]))
+    if M * N * max(K, 8) > 6e8:   # keep the fp64 oracle in seconds
+        N = int(rng.choice([33, 64, 100, 257]))
+    nv = int(rng.integers(1, 4))
+    bv = int(rng.integers(0, nv + 1)) if N >= 3 * nv else 0
+    nb = int(rng.choice([1, 2, 4, 9, 15, 16, 23]))
+    bern = float(rng.choice([0.0, 0.0, 0.3, 1.0]))
+    pois = float(rng.choice([0.0, 0.0, 0.2])) if bern < 1.0 else 0.0
+    kw = dict(M=M, N=N, K=K, n_views=min(nv, N), batch_views=min(bv, N), n_batches=min(nb, max(M, 1)),
+              bernoulli_frac=bern, poisson_frac=pois, nan_frac=float(rng.choice([0.0, 0.0, 0.05, 0.5])),
+              weights=bool(rng.integers(0, 2)), col_params=bool(rng.integers(0, 2)), scale=0.4,
+              xreg=rng.choice([None, "l2", "group"]), yreg=rng.choice([None, "fsard", "ard", "group"]))
+    try:
+        p = make_problem(seed=int(rng.integers(1 << 30)), **kw)
+    except Exception as e:   # a shape the generator itself cannot build (e.g. more batches than rows)
+        print(f"case {c}: generator skipped {kw}: {e}")
+        continue
+    to_context(p, ctx)
+    o = ctx.make_opts(update_X=True, update_Y=True)
+    ctx.epoch_begin(o)
+    loss, _ = ctx.epoch_loss()
+    gx, gy = ctx.get_grad("X"), ctx.get_grad("Y")
+    m = to_oracle(p)
+    m.m.n_xreg = 0; m.m.n_yreg = 0
+    lo, go = m.loss_and_grads(update_X=True, update_Y=True)
+    el = abs(loss - go["data_loss"]) / (abs(go["data_loss"]) + 1e-6)
+    ex, ey = rel_err(gx, go["X"]), rel_err(gy, go["Y"])
+    el2 = 0.0
+    if p["batch_views"] or kw["col_params"]:
+        o2 = ctx.make_opts(update_col_layers=True)
+        ctx.epoch_begin(o2)
+        ctx.epoch_loss()
+        m2 = to_oracle(p)
+        m2.m.has_colreg = 0; m2.m.has_batchreg = 0
+        _, g2 = m2.loss_and_grads(update_col_layers=True)
+        el2 = max(rel_err(ctx.get_grad("mu"), g2["mu"]), rel_err(ctx.get_grad("logsigma"), g2["logsigma"]))
+        for v in range(len(p["batch_views"])):
+            el2 = max(el2, rel_err(ctx.get_grad("theta", v), g2["theta"][v]), rel_err(ctx.get_grad("logdelta", v), g2["logdelta"][v]))
+    bad = el > 2e-5 or ex > 2e-4 or ey > 2e-4 or el2 > 2e-4 or not np.isfinite([el, ex, ey, el2]).all()
+    worst = dict(loss=max(worst["loss"], el), gx=max(worst["gx"], ex), gy=max(worst["gy"], ey), layer=max(worst["layer"], el2))
+    print(f"case {c:3d} {'FAIL' if bad else 'ok  '} M={M} N={N} K={K} views={nv}/{bv} nb={nb} bern={bern} pois={pois} nan={kw['nan_frac']}: "
+          f"loss {el:.1e} gX {ex:.1e} gY {ey:.1e} layers {el2:.1e}", flush=True)
+print("worst:", worst)
