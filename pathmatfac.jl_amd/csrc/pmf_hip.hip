@@ -1267,43 +1267,69 @@ static int ensure_tile_flags(pmf_ctx *c) {
 // order: grad(Y) is bitwise reproducible).  The work sequence (pmf_fused_kernel) is segment-major, then row panel,
 // then tile; workgroup g owns [g*T/G, (g+1)*T/G).  Inside segment cs (tiles [cs*S, cs*S + n_rp*tps_cs) of the
 // sequence) it touched tile ti iff its range, taken relative to the segment start, contains an index == ti mod tps_cs.
-__global__ void k_gy_reduce(const float *__restrict__ slabs, int64_t stride, int G, const int64_t *__restrict__ wgb,
-                            int64_t n_rp, int tps, int n_ct, int n_cseg, int Kp, int64_t N, float *__restrict__ gY) {
-  // one workgroup per column tile: the set of contributing workgroups is the same for all its 32 x Kp elements
+__global__ __launch_bounds__(64) void k_gy_reduce(const float *__restrict__ slabs, int64_t stride, int G,
+                                                  const int64_t *__restrict__ wgb, int64_t n_rp, int tps, int n_ct,
+                                                  int n_cseg, int Kp, int64_t N, float *__restrict__ gY) {
+  // blockIdx.x = column tile, blockIdx.y = 256-float slice of its 32 x Kp elements (one float4 per thread).  The set of
+  // contributing workgroups is the same for the whole tile: it is listed once (uniform scalar work), then the slabs are
+  // summed four at a time so that four independent loads are in flight per thread.
+  __shared__ int contrib[1024];
+  __shared__ int n_contrib;
   const int ct = blockIdx.x;
   int cs = ct / tps;
   if (cs > n_cseg - 1) cs = n_cseg - 1;
   const int tps_cs = cs == n_cseg - 1 ? n_ct - (n_cseg - 1) * tps : tps;
   const int ti = ct - cs * tps;
   const int64_t s0 = (int64_t)cs * n_rp * tps, s1 = s0 + n_rp * tps_cs;   // the segment's slice of the sequence
-  auto owner = [&](int64_t u) {   // last g with wgb[g] <= u
-    int lo = 0, hi = G - 1;
-    while (lo < hi) {
-      const int mid = (lo + hi + 1) >> 1;
-      if (wgb[mid] <= u) lo = mid; else hi = mid - 1;
-    }
-    return lo;
-  };
-  const int g_lo = owner(s0), g_hi = owner(s1 - 1);
-  const int64_t e0 = (int64_t)ct * 32 * Kp;
-  const int64_t rem = (int64_t)Kp * N - e0;
-  const int nel = rem > 32 * Kp ? 32 * Kp : (int)rem;
-  for (int q = threadIdx.x * 4; q < nel; q += blockDim.x * 4) {    // nel is a multiple of Kp, Kp of 32
-    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int g = g_lo; g <= g_hi; ++g) {
+  if (threadIdx.x == 0) {
+    auto owner = [&](int64_t u) {   // last g with wgb[g] <= u
+      int lo = 0, hi = G - 1;
+      while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (wgb[mid] <= u) lo = mid; else hi = mid - 1;
+      }
+      return lo;
+    };
+    const int g_lo = owner(s0), g_hi = owner(s1 - 1);
+    int n = 0;
+    for (int g = g_lo; g <= g_hi && n < 1024; ++g) {
       int64_t lo = wgb[g], hi = wgb[g + 1];
       if (lo < s0) lo = s0;
       if (hi > s1) hi = s1;
       if (hi <= lo) continue;
       const int64_t first = (lo - s0) % tps_cs;
       const int64_t d = (ti - first + tps_cs) % tps_cs;
-      if (d < hi - lo) {
-        const float4 v = *reinterpret_cast<const float4 *>(slabs + (int64_t)g * stride + e0 + q);
-        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
-      }
+      if (d < hi - lo) contrib[n++] = g;
     }
-    *reinterpret_cast<float4 *>(gY + e0 + q) = acc;
+    n_contrib = n;
   }
+  __syncthreads();
+  const int64_t e0 = (int64_t)ct * 32 * Kp;
+  const int64_t rem = (int64_t)Kp * N - e0;
+  const int nel = rem > 32 * Kp ? 32 * Kp : (int)rem;   // a multiple of Kp, Kp a multiple of 32
+  const int q = (blockIdx.y * 64 + threadIdx.x) * 4;
+  if (q >= nel) return;
+  const float *base = slabs + e0 + q;
+  const int n = n_contrib;
+  float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0, a2 = a0, a3 = a0;
+  int c = 0;
+  for (; c + 4 <= n; c += 4) {   // fixed order: ((s0 + s4 + ...) + (s1 + s5 + ...)) + ... -> bitwise reproducible
+    const float4 v0 = *reinterpret_cast<const float4 *>(base + (int64_t)contrib[c] * stride);
+    const float4 v1 = *reinterpret_cast<const float4 *>(base + (int64_t)contrib[c + 1] * stride);
+    const float4 v2 = *reinterpret_cast<const float4 *>(base + (int64_t)contrib[c + 2] * stride);
+    const float4 v3 = *reinterpret_cast<const float4 *>(base + (int64_t)contrib[c + 3] * stride);
+    a0.x += v0.x; a0.y += v0.y; a0.z += v0.z; a0.w += v0.w;
+    a1.x += v1.x; a1.y += v1.y; a1.z += v1.z; a1.w += v1.w;
+    a2.x += v2.x; a2.y += v2.y; a2.z += v2.z; a2.w += v2.w;
+    a3.x += v3.x; a3.y += v3.y; a3.z += v3.z; a3.w += v3.w;
+  }
+  for (; c < n; ++c) {
+    const float4 v = *reinterpret_cast<const float4 *>(base + (int64_t)contrib[c] * stride);
+    a0.x += v.x; a0.y += v.y; a0.z += v.z; a0.w += v.w;
+  }
+  *reinterpret_cast<float4 *>(gY + e0 + q) =
+      make_float4((a0.x + a1.x) + (a2.x + a3.x), (a0.y + a1.y) + (a2.y + a3.y), (a0.z + a1.z) + (a2.z + a3.z),
+                  (a0.w + a1.w) + (a2.w + a3.w));
 }
 
 // Cost-balanced split of the fused kernel's work sequence (segment-major, row panel, tile) into `grid` contiguous
@@ -1490,7 +1516,8 @@ static int launch_fused(pmf_ctx *c, bool want_gx, bool want_gy) {
   PMFCHK(rc);
   HIPCHK(hipEventRecord(ev.second, c->stream));   // the events bracket pmf_fused_kernel alone (= rocprofv3's kernel duration)
   if (want_gy && !(a.dbg & 8)) {
-    k_gy_reduce<<<(unsigned)a.n_ct, 256, 0, c->stream>>>(c->gy_slabs, slab_stride, grid, c->wg_begin, n_rp, a.tps, a.n_ct,
+    if (grid > 1024) return pmf_fail("internal: k_gy_reduce supports at most 1024 workgroups");
+    k_gy_reduce<<<dim3((unsigned)a.n_ct, (unsigned)(32 * c->Kp / 256)), 64, 0, c->stream>>>(c->gy_slabs, slab_stride, grid, c->wg_begin, n_rp, a.tps, a.n_ct,
                                                                     a.n_cseg, c->Kp, c->N, c->P[1].g);
     HIPCHK(hipGetLastError());
   }
