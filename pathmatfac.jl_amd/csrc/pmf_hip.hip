@@ -1382,13 +1382,14 @@ static int compute_work_split(pmf_ctx *c, int grid, int64_t n_rp, int64_t n_ct, 
   return 0;
 }
 
-template <int KB, int NW>
+template <int KB, int NW, int RBW>
 static int launch_fused_t(pmf_ctx *c, const FusedArgs &a, int grid, bool batch, bool mixed) {
-  const size_t lds = pmf_fused_lds_bytes<KB, NW>() + (batch ? FusedCfg<KB, NW>::lds_batch_extra : 0);
+  using Cfg = FusedCfg<KB, NW, RBW>;
+  const size_t lds = Cfg::lds_bytes + (batch ? Cfg::lds_batch_extra : 0);
   const bool full = a.want_gx && a.want_gy && a.dbg == 0;
   void (*kern)(const FusedArgs) = nullptr;
   const int bmode = !batch ? 0 : (a.btd ? 1 : 2);
-#define PMF_PICK(BM, MX, FU) pmf_fused_kernel<KB, NW, BM, MX, FU>
+#define PMF_PICK(BM, MX, FU) pmf_fused_kernel<KB, NW, RBW, BM, MX, FU>
   if (full) {
     if (bmode == 0) kern = mixed ? PMF_PICK(0, true, true) : PMF_PICK(0, false, true);
     else if (bmode == 1) kern = mixed ? PMF_PICK(1, true, true) : PMF_PICK(1, false, true);
@@ -1431,9 +1432,15 @@ static int harvest_events(pmf_ctx *c) {
 }
 
 static int launch_fused(pmf_ctx *c, bool want_gx, bool want_gy) {
-  const char *nwenv = getenv("PMF_NW");
-  const int NW = c->KB <= 2 ? ((nwenv && atoi(nwenv) == 4) ? 4 : 8) : 4;
-  const int BM = 32 * NW;
+  // variant: waves per workgroup NW and 32-row blocks per wave RBW (the workgroup's row panel is 32*NW*RBW rows)
+  //   K <= 32 : 8 waves x 2 row blocks (per-tile overheads amortised over twice the MFMA work)
+  //   K <= 64 : 8 waves x 1          K <= 128 : 4 waves x 1 (one wave per SIMD, whole register file)
+  // PMF_RBW=1|2 overrides RBW for K <= 64 (K <= 64 with RBW = 2 runs 4 waves x 2: development comparison)
+  const char *rbwenv = getenv("PMF_RBW");
+  int NW = c->KB <= 2 ? 8 : 4, RBW = c->KB == 1 ? 2 : 1;
+  if (rbwenv && c->KB <= 2) RBW = atoi(rbwenv) == 2 ? 2 : 1;
+  if (c->KB == 2 && RBW == 2) NW = 4;
+  const int BM = 32 * NW * RBW;
   const int64_t n_rp = (c->M + BM - 1) / BM;
   const int64_t n_ct = (c->N + PMF_BN - 1) / PMF_BN;  // column tiles
   // Column segments.  The work split is balanced to a tile whatever the segmentation, so the segment length only trades
@@ -1442,7 +1449,7 @@ static int launch_fused(pmf_ctx *c, bool want_gx, bool want_gy) {
   //   (b) k_gy_reduce, which reads the private slabs of the ~G*tps/n_ct + 1 workgroups that visited a column tile
   //       (Kp*N*4 bytes each at ~4 TB/s).
   // tps* = sqrt(a/b) minimises a/tps + b*tps.
-  const int grid0 = (int)std::min<int64_t>(n_rp * n_ct, (int64_t)c->n_cu * ((NW == 4 && c->KB <= 2) ? 2 : 1));
+  const int grid0 = (int)std::min<int64_t>(n_rp * n_ct, (int64_t)c->n_cu);
   const double tiles_per_wg = (double)(n_rp * n_ct) / grid0;
   const double a_cost = tiles_per_wg * 8e-6;
   const double b_cost = (double)grid0 * (double)c->Kp * (double)c->N * 4.0 / ((double)n_ct * 4e12);
@@ -1452,7 +1459,7 @@ static int launch_fused(pmf_ctx *c, bool want_gx, bool want_gy) {
   // prologue, so a 5-tile last segment once made one workgroup 20 % late)
   const int64_t n_cseg = std::max<int64_t>(1, n_ct / tiles_per_seg);
   const int64_t n_tiles = n_rp * n_ct;   // the kernel's work items, dealt out in contiguous, balanced ranges
-  const int grid = (int)std::min<int64_t>(n_tiles, (int64_t)c->n_cu * ((NW == 4 && c->KB <= 2) ? 2 : 1));
+  const int grid = (int)std::min<int64_t>(n_tiles, (int64_t)c->n_cu);
   if (grid > c->loss_cap) {
     PMFCHK(dev_alloc(&c->loss_partial, (size_t)grid));
     c->loss_cap = grid;
@@ -1506,11 +1513,13 @@ static int launch_fused(pmf_ctx *c, bool want_gx, bool want_gy) {
   auto &ev = c->ev_pool[c->ev_used++];
   HIPCHK(hipEventRecord(ev.first, c->stream));
   int rc = 0;
-  switch (c->KB) {
-    case 1: rc = NW == 8 ? launch_fused_t<1, 8>(c, a, grid, batch, c->mixed) : launch_fused_t<1, 4>(c, a, grid, batch, c->mixed); break;
-    case 2: rc = NW == 8 ? launch_fused_t<2, 8>(c, a, grid, batch, c->mixed) : launch_fused_t<2, 4>(c, a, grid, batch, c->mixed); break;
-    case 3: rc = launch_fused_t<3, 4>(c, a, grid, batch, c->mixed); break;
-    case 4: rc = launch_fused_t<4, 4>(c, a, grid, batch, c->mixed); break;
+  switch (c->KB * 10 + RBW) {
+    case 11: rc = launch_fused_t<1, 8, 1>(c, a, grid, batch, c->mixed); break;
+    case 12: rc = launch_fused_t<1, 8, 2>(c, a, grid, batch, c->mixed); break;
+    case 21: rc = launch_fused_t<2, 8, 1>(c, a, grid, batch, c->mixed); break;
+    case 22: rc = launch_fused_t<2, 4, 2>(c, a, grid, batch, c->mixed); break;
+    case 31: rc = launch_fused_t<3, 4, 1>(c, a, grid, batch, c->mixed); break;
+    case 41: rc = launch_fused_t<4, 4, 1>(c, a, grid, batch, c->mixed); break;
     default: return pmf_fail("unsupported KB=%d", c->KB);
   }
   PMFCHK(rc);
