@@ -2,6 +2,7 @@
 // include/pmf_hip.h.  Written for CDNA4 only (wave64, v_mfma_f32_32x32x2_f32, 160 KiB LDS).
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <chrono>
 #include <cmath>
 #include <cstdarg>
@@ -97,6 +98,7 @@ struct pmf_ctx {
   std::vector<uint8_t> h_kind;    // host copy of the per-column noise kind (cost model of the work split)
   int64_t *wg_begin = nullptr;    // [grid + 1] device: first work item of each workgroup (fused kernel)
   std::vector<int64_t> h_wg_begin;
+  int32_t *c_off = nullptr, *c_idx = nullptr;   // per column tile: the workgroups that visit it (CSR; for k_gy_reduce)
   int64_t wgb_key[8] = {-1, -1, -1, -1, -1, -1, -1, -1};   // geometry the cached split was computed for
   int64_t kind_version = 0;
   float *gy_slabs = nullptr;      // [grid][Kp x N] private per-workgroup gY partial sums of the fused kernel
@@ -726,7 +728,7 @@ extern "C" int pmf_destroy(pmf_ctx *c) {
   dev_free(&c->bor); dev_free(&c->btab); dev_free(&c->btd); c->btd_cap = 0; c->btd_ok = false; dev_free(&c->d_views); dev_free(&c->d_val_view);
   dev_free(&c->colmeta); dev_free(&c->colw); dev_free(&c->colp);
   dev_free(&c->ard_alpha); dev_free(&c->ard_beta);
-  dev_free(&c->wg_begin); dev_free(&c->gy_slabs); dev_free(&c->loss_partial); dev_free(&c->reg_partial); dev_free(&c->d_loss);
+  dev_free(&c->wg_begin); dev_free(&c->c_off); dev_free(&c->c_idx); dev_free(&c->gy_slabs); dev_free(&c->loss_partial); dev_free(&c->reg_partial); dev_free(&c->d_loss);
   if (c->h_loss) (void)hipHostFree(c->h_loss);
   if (c->scratch) (void)hipFree(c->scratch);
   for (auto &e : c->ev_pool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
@@ -1267,64 +1269,35 @@ static int ensure_tile_flags(pmf_ctx *c) {
 // order: grad(Y) is bitwise reproducible).  The work sequence (pmf_fused_kernel) is segment-major, then row panel,
 // then tile; workgroup g owns [g*T/G, (g+1)*T/G).  Inside segment cs (tiles [cs*S, cs*S + n_rp*tps_cs) of the
 // sequence) it touched tile ti iff its range, taken relative to the segment start, contains an index == ti mod tps_cs.
-__global__ __launch_bounds__(64) void k_gy_reduce(const float *__restrict__ slabs, int64_t stride, int G,
-                                                  const int64_t *__restrict__ wgb, int64_t n_rp, int tps, int n_ct,
-                                                  int n_cseg, int Kp, int64_t N, float *__restrict__ gY) {
-  // blockIdx.x = column tile, blockIdx.y = 256-float slice of its 32 x Kp elements (one float4 per thread).  The set of
-  // contributing workgroups is the same for the whole tile: it is listed once (uniform scalar work), then the slabs are
-  // summed four at a time so that four independent loads are in flight per thread.
-  __shared__ int contrib[1024];
-  __shared__ int n_contrib;
+__global__ __launch_bounds__(64) void k_gy_reduce(const float *__restrict__ slabs, int64_t stride,
+                                                  const int32_t *__restrict__ c_off, const int32_t *__restrict__ c_idx,
+                                                  int Kp, int64_t N, float *__restrict__ gY) {
+  // blockIdx.x = column tile, blockIdx.y = 256-float slice of its 32 x Kp elements (one float4 per thread).  The
+  // workgroups that visited the tile are listed in c_idx[c_off[ct] .. c_off[ct+1]) (built on the host with the work
+  // split, compute_work_split); their slabs are summed four at a time so that four independent loads are in flight.
   const int ct = blockIdx.x;
-  int cs = ct / tps;
-  if (cs > n_cseg - 1) cs = n_cseg - 1;
-  const int tps_cs = cs == n_cseg - 1 ? n_ct - (n_cseg - 1) * tps : tps;
-  const int ti = ct - cs * tps;
-  const int64_t s0 = (int64_t)cs * n_rp * tps, s1 = s0 + n_rp * tps_cs;   // the segment's slice of the sequence
-  if (threadIdx.x == 0) {
-    auto owner = [&](int64_t u) {   // last g with wgb[g] <= u
-      int lo = 0, hi = G - 1;
-      while (lo < hi) {
-        const int mid = (lo + hi + 1) >> 1;
-        if (wgb[mid] <= u) lo = mid; else hi = mid - 1;
-      }
-      return lo;
-    };
-    const int g_lo = owner(s0), g_hi = owner(s1 - 1);
-    int n = 0;
-    for (int g = g_lo; g <= g_hi && n < 1024; ++g) {
-      int64_t lo = wgb[g], hi = wgb[g + 1];
-      if (lo < s0) lo = s0;
-      if (hi > s1) hi = s1;
-      if (hi <= lo) continue;
-      const int64_t first = (lo - s0) % tps_cs;
-      const int64_t d = (ti - first + tps_cs) % tps_cs;
-      if (d < hi - lo) contrib[n++] = g;
-    }
-    n_contrib = n;
-  }
-  __syncthreads();
   const int64_t e0 = (int64_t)ct * 32 * Kp;
   const int64_t rem = (int64_t)Kp * N - e0;
   const int nel = rem > 32 * Kp ? 32 * Kp : (int)rem;   // a multiple of Kp, Kp a multiple of 32
   const int q = (blockIdx.y * 64 + threadIdx.x) * 4;
   if (q >= nel) return;
   const float *base = slabs + e0 + q;
-  const int n = n_contrib;
+  const int c0 = c_off[ct], n = c_off[ct + 1] - c0;
+  const int32_t *ci = c_idx + c0;
   float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0, a2 = a0, a3 = a0;
   int c = 0;
   for (; c + 4 <= n; c += 4) {   // fixed order: ((s0 + s4 + ...) + (s1 + s5 + ...)) + ... -> bitwise reproducible
-    const float4 v0 = *reinterpret_cast<const float4 *>(base + (int64_t)contrib[c] * stride);
-    const float4 v1 = *reinterpret_cast<const float4 *>(base + (int64_t)contrib[c + 1] * stride);
-    const float4 v2 = *reinterpret_cast<const float4 *>(base + (int64_t)contrib[c + 2] * stride);
-    const float4 v3 = *reinterpret_cast<const float4 *>(base + (int64_t)contrib[c + 3] * stride);
+    const float4 v0 = *reinterpret_cast<const float4 *>(base + (int64_t)ci[c] * stride);
+    const float4 v1 = *reinterpret_cast<const float4 *>(base + (int64_t)ci[c + 1] * stride);
+    const float4 v2 = *reinterpret_cast<const float4 *>(base + (int64_t)ci[c + 2] * stride);
+    const float4 v3 = *reinterpret_cast<const float4 *>(base + (int64_t)ci[c + 3] * stride);
     a0.x += v0.x; a0.y += v0.y; a0.z += v0.z; a0.w += v0.w;
     a1.x += v1.x; a1.y += v1.y; a1.z += v1.z; a1.w += v1.w;
     a2.x += v2.x; a2.y += v2.y; a2.z += v2.z; a2.w += v2.w;
     a3.x += v3.x; a3.y += v3.y; a3.z += v3.z; a3.w += v3.w;
   }
   for (; c < n; ++c) {
-    const float4 v = *reinterpret_cast<const float4 *>(base + (int64_t)contrib[c] * stride);
+    const float4 v = *reinterpret_cast<const float4 *>(base + (int64_t)ci[c] * stride);
     a0.x += v.x; a0.y += v.y; a0.z += v.z; a0.w += v.w;
   }
   *reinterpret_cast<float4 *>(gY + e0 + q) =
@@ -1375,9 +1348,33 @@ static int compute_work_split(pmf_ctx *c, int grid, int64_t n_rp, int64_t n_ct, 
     c->h_wg_begin[(size_t)g] = std::min(idx, T);
   }
   c->h_wg_begin[(size_t)grid] = T;
+  // which workgroups visit a column tile: inside segment cs (items [s0, s1) of the sequence) workgroup g visits tile
+  // ti iff its range, clipped to the segment, contains an index == ti modulo the segment's tile count
+  std::vector<int32_t> h_off((size_t)n_ct + 1, 0), h_idx;
+  const std::vector<int64_t> &wb = c->h_wg_begin;
+  for (int64_t ct = 0; ct < n_ct; ++ct) {
+    const int64_t cs = std::min<int64_t>(ct / tps, n_cseg - 1);
+    const int64_t tps_cs = seg_nt[(size_t)cs], ti = ct - cs * tps;
+    const int64_t s0 = cs * n_rp * tps, s1 = s0 + n_rp * tps_cs;
+    int g_lo = (int)(std::upper_bound(wb.begin(), wb.begin() + grid, s0) - wb.begin()) - 1;
+    if (g_lo < 0) g_lo = 0;
+    for (int g = g_lo; g < grid && wb[(size_t)g] < s1; ++g) {
+      const int64_t lo = std::max(wb[(size_t)g], s0), hi = std::min(wb[(size_t)g + 1], s1);
+      if (hi <= lo) continue;
+      const int64_t first = (lo - s0) % tps_cs;
+      const int64_t d = (ti - first + tps_cs) % tps_cs;
+      if (d < hi - lo) h_idx.push_back(g);
+    }
+    h_off[(size_t)ct + 1] = (int32_t)h_idx.size();
+  }
+  if (h_idx.empty()) h_idx.push_back(0);
   PMFCHK(dev_alloc(&c->wg_begin, (size_t)grid + 1, false));
+  PMFCHK(dev_alloc(&c->c_off, (size_t)n_ct + 1, false));
+  PMFCHK(dev_alloc(&c->c_idx, h_idx.size(), false));
   HIPCHK(hipMemcpyAsync(c->wg_begin, c->h_wg_begin.data(), sizeof(int64_t) * ((size_t)grid + 1), hipMemcpyHostToDevice, c->stream));
-  HIPCHK(hipStreamSynchronize(c->stream));   // h_wg_begin is pageable host memory
+  HIPCHK(hipMemcpyAsync(c->c_off, h_off.data(), sizeof(int32_t) * h_off.size(), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(hipMemcpyAsync(c->c_idx, h_idx.data(), sizeof(int32_t) * h_idx.size(), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));   // the sources are pageable host memory
   memcpy(c->wgb_key, key, sizeof(key));
   return 0;
 }
@@ -1525,9 +1522,8 @@ static int launch_fused(pmf_ctx *c, bool want_gx, bool want_gy) {
   PMFCHK(rc);
   HIPCHK(hipEventRecord(ev.second, c->stream));   // the events bracket pmf_fused_kernel alone (= rocprofv3's kernel duration)
   if (want_gy && !(a.dbg & 8)) {
-    if (grid > 1024) return pmf_fail("internal: k_gy_reduce supports at most 1024 workgroups");
-    k_gy_reduce<<<dim3((unsigned)a.n_ct, (unsigned)(32 * c->Kp / 256)), 64, 0, c->stream>>>(c->gy_slabs, slab_stride, grid, c->wg_begin, n_rp, a.tps, a.n_ct,
-                                                                    a.n_cseg, c->Kp, c->N, c->P[1].g);
+    k_gy_reduce<<<dim3((unsigned)a.n_ct, (unsigned)(32 * c->Kp / 256)), 64, 0, c->stream>>>(c->gy_slabs, slab_stride, c->c_off, c->c_idx,
+                                                                                        c->Kp, c->N, c->P[1].g);
     HIPCHK(hipGetLastError());
   }
   return 0;
@@ -1623,7 +1619,7 @@ extern "C" int pmf_epoch_begin(pmf_ctx *c, const pmf_fit_opts *o) {
   const bool fused = o->update_X || o->update_Y || !o->update_col_layers;
   // gradients are accumulated with atomics: start every epoch from zero
   if (o->update_X) HIPCHK(hipMemsetAsync(c->P[0].g, 0, sizeof(float) * (size_t)c->P[0].n, c->stream));
-  if (o->update_Y) HIPCHK(hipMemsetAsync(c->P[1].g, 0, sizeof(float) * (size_t)c->P[1].n, c->stream));
+  // (grad(Y) needs no clearing: k_gy_reduce overwrites every element)
   if (o->update_col_layers)
     for (int w = 2; w < 6; ++w)
       if (c->P[w].n) HIPCHK(hipMemsetAsync(c->P[w].g, 0, sizeof(float) * (size_t)c->P[w].n, c->stream));
