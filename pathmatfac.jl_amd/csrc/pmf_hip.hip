@@ -1430,11 +1430,12 @@ static int harvest_events(pmf_ctx *c) {
 
 static int launch_fused(pmf_ctx *c, bool want_gx, bool want_gy) {
   // variant: waves per workgroup NW and 32-row blocks per wave RBW (the workgroup's row panel is 32*NW*RBW rows)
-  //   K <= 32 : 8 waves x 2 row blocks (per-tile overheads amortised over twice the MFMA work)
+  //   K <= 32 : 8 waves x 2 row blocks (per-tile overheads amortised over twice the MFMA work; x 1 with batch layers)
   //   K <= 64 : 8 waves x 1          K <= 128 : 4 waves x 1 (one wave per SIMD, whole register file)
   // PMF_RBW=1|2 overrides RBW for K <= 64 (K <= 64 with RBW = 2 runs 4 waves x 2: development comparison)
   const char *rbwenv = getenv("PMF_RBW");
-  int NW = c->KB <= 2 ? 8 : 4, RBW = c->KB == 1 ? 2 : 1;
+  // (the batch-layer epilogue of two row blocks does not fit the 256-register budget: RBW = 2 spills and is 1.5x slower)
+  int NW = c->KB <= 2 ? 8 : 4, RBW = (c->KB == 1 && c->n_bv == 0) ? 2 : 1;
   if (rbwenv && c->KB <= 2) RBW = atoi(rbwenv) == 2 ? 2 : 1;
   if (c->KB == 2 && RBW == 2) NW = 4;
   const int BM = 32 * NW * RBW;
