@@ -166,7 +166,12 @@ def main():
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / F32_MFMA_PEAK_TFLOPS, "traffic": None,
                          "kernel": "pmf_fused_kernel", "kernel_ms": k_ms, "launches": k_n,
-                         "hbm_stream_GBps": 4.0 * Ml * N / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0},
+                         "hbm_stream_GBps": 4.0 * Ml * N / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0,
+                         # the co-bound.  Algorithmic HBM bytes of one epoch on this rank = D once
+                         # + parameter / optimizer traffic (p, g, state read + p, state written) + the Y-reg beta
+                         "hbm_frac": ((4.0 * Ml * N + 4.0 * K * (Ml + N) * (7 if args.optimizer == "adam" else 5)
+                                       + 4.0 * K * N) / (dt / args.steps)) / 8.0e12,
+                         "hbm_peak_GBps": 8000.0},
             "loss_first": losses[0], "loss_last": losses[-1],
         }
         # HBM traffic of the dominant kernel: measured offline with rocprofv3 PMC passes (scripts/profile.sh) and
