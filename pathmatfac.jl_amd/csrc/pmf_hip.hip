@@ -14,6 +14,7 @@
 
 #include "../../include/pmf_hip.h"
 #include "pmf_fused.hip.inc"
+#include "pmf_layers.hip.inc"
 
 // ------------------------------------------------------------------------------------------------
 // error handling
@@ -75,6 +76,8 @@ struct pmf_ctx {
   int32_t *bor = nullptr;
   float2 *btab = nullptr;
   ViewDesc *d_views = nullptr;    // device copy of `views` for the fused kernel's global-gather fallback
+  float2 *LG = nullptr;           // [N][16] {S_G, S_Q} of the layer pass (pmf_layers.hip.inc)
+  int64_t LG_cap = 0;
   float2 *btd = nullptr;          // dense per-column batch table [ceil(N/32)*32][16] (fused kernel, LDS path); see k_dense_btab
   int64_t btd_cap = 0;
   bool btd_ok = false;            // every view has <= 15 batches: the dense table is usable
@@ -725,7 +728,7 @@ extern "C" int pmf_destroy(pmf_ctx *c) {
   for (auto &b : c->P) param_free(b);
   if (c->own_D) dev_free(&c->D);
   dev_free(&c->tflags);
-  dev_free(&c->bor); dev_free(&c->btab); dev_free(&c->btd); c->btd_cap = 0; c->btd_ok = false; dev_free(&c->d_views); dev_free(&c->d_val_view);
+  dev_free(&c->bor); dev_free(&c->btab); dev_free(&c->btd); c->btd_cap = 0; c->btd_ok = false; dev_free(&c->LG); c->LG_cap = 0; dev_free(&c->d_views); dev_free(&c->d_val_view);
   dev_free(&c->colmeta); dev_free(&c->colw); dev_free(&c->colp);
   dev_free(&c->ard_alpha); dev_free(&c->ard_beta);
   dev_free(&c->wg_begin); dev_free(&c->c_off); dev_free(&c->c_idx); dev_free(&c->gy_slabs); dev_free(&c->loss_partial); dev_free(&c->reg_partial); dev_free(&c->d_loss);
@@ -771,7 +774,7 @@ static int data_shape_changed(pmf_ctx *c, int64_t M, int64_t N) {
   c->views.clear();
   c->val_off.clear();
   c->bvb_off.clear();
-  dev_free(&c->bor); dev_free(&c->btab); dev_free(&c->btd); c->btd_cap = 0; c->btd_ok = false; dev_free(&c->d_views); dev_free(&c->d_val_view);
+  dev_free(&c->bor); dev_free(&c->btab); dev_free(&c->btd); c->btd_cap = 0; c->btd_ok = false; dev_free(&c->LG); c->LG_cap = 0; dev_free(&c->d_views); dev_free(&c->d_val_view);
   PMFCHK(dev_alloc(&c->colmeta, (size_t)N));
   PMFCHK(dev_alloc(&c->colw, (size_t)N));
   PMFCHK(dev_alloc(&c->colp, (size_t)N));
@@ -1578,6 +1581,56 @@ static int launch_layer_grad(pmf_ctx *c, const pmf_fit_opts *o, bool with_loss) 
   return 0;
 }
 
+// Layer-parameter gradients through the MFMA layer pass (its own loss only in layer-only epochs); K <= 64 and <= 15 batches per view, otherwise the
+// VALU kernel above (PMF_LAYER_OLD=1 forces it, for comparison).
+static bool layer_pass_eligible(pmf_ctx *c) {
+  const char *e = getenv("PMF_LAYER_OLD");
+  if (e && atoi(e) == 1) return false;
+  return c->KB <= 2 && (c->n_bv == 0 || c->btd_ok);
+}
+static int launch_layer_pass(pmf_ctx *c, const pmf_fit_opts *o, bool with_loss) {
+  const int64_t n_ct = (c->N + PMF_BN - 1) / PMF_BN, n_rp = (c->M + 255) / 256;
+  const int64_t n_seg = (n_ct + PMF_LS - 1) / PMF_LS;
+  int64_t R = std::max<int64_t>(1, std::min<int64_t>(n_rp, (4ll * c->n_cu + n_seg - 1) / n_seg));
+  const int grid = (int)std::min<int64_t>(n_seg * R, c->n_cu);
+  if (c->N * 16 > c->LG_cap) {
+    PMFCHK(dev_alloc(&c->LG, (size_t)(c->N * 16), false));
+    c->LG_cap = c->N * 16;
+  }
+  HIPCHK(hipMemsetAsync(c->LG, 0, sizeof(float2) * (size_t)(c->N * 16), c->stream));
+  if (with_loss) {
+    if (grid > c->loss_cap) {
+      PMFCHK(dev_alloc(&c->loss_partial, (size_t)grid));
+      c->loss_cap = grid;
+    }
+    c->n_macro = grid;
+  }
+  LayerPassArgs a;
+  memset(&a, 0, sizeof(a));
+  a.D = c->D; a.nRB = c->nRB; a.X = c->P[0].p; a.Y = c->P[1].p; a.colp = c->colp; a.bor = c->bor;
+  a.btd = c->n_bv > 0 ? c->btd : nullptr; a.LG = c->LG; a.loss_partial = with_loss ? c->loss_partial : nullptr;
+  a.M = c->M; a.N = c->N; a.n_bv = c->n_bv; a.n_ct = (int)n_ct; a.n_rp = (int)n_rp; a.n_seg = (int)n_seg; a.R = (int)R;
+  void (*kern)(const LayerPassArgs) = nullptr;
+  size_t lds = 0;
+  if (c->KB == 1) { kern = c->mixed ? pmf_layer_kernel<1, true> : pmf_layer_kernel<1, false>; lds = LayerCfg<1>::lds_bytes; }
+  else { kern = c->mixed ? pmf_layer_kernel<2, true> : pmf_layer_kernel<2, false>; lds = LayerCfg<2>::lds_bytes; }
+  HIPCHK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, c->stream, a);
+  HIPCHK(hipGetLastError());
+  LayerMapArgs m;
+  memset(&m, 0, sizeof(m));
+  const int fl = o->frozen_layers;
+  m.LG = c->LG; m.btd = a.btd; m.colp = c->colp; m.N = c->N; m.n_bv = c->n_bv;
+  m.g_logsigma = (fl & 1) ? nullptr : c->P[2].g;
+  m.g_logdelta = ((fl & 2) || c->n_bv == 0) ? nullptr : c->P[4].g;
+  m.g_mu = (fl & 4) ? nullptr : c->P[3].g;
+  m.g_theta = ((fl & 8) || c->n_bv == 0) ? nullptr : c->P[5].g;
+  for (int v = 0; v < c->n_bv; ++v) { m.views[v] = c->views[v]; m.val_off[v] = c->val_off[v]; }
+  k_layer_map<<<nblocks(c->N, 256), 256, 0, c->stream>>>(m);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
 static int check_ready(pmf_ctx *c) {
   if (!c->D) return pmf_fail("data not set");
   if (c->K == 0) return pmf_fail("factors not set");
@@ -1625,7 +1678,10 @@ extern "C" int pmf_epoch_begin(pmf_ctx *c, const pmf_fit_opts *o) {
     for (int w = 2; w < 6; ++w)
       if (c->P[w].n) HIPCHK(hipMemsetAsync(c->P[w].g, 0, sizeof(float) * (size_t)c->P[w].n, c->stream));
   if (fused) PMFCHK(launch_fused(c, o->update_X != 0, o->update_Y != 0));
-  if (o->update_col_layers) PMFCHK(launch_layer_grad(c, o, !fused));
+  if (o->update_col_layers) {
+    if (layer_pass_eligible(c)) PMFCHK(launch_layer_pass(c, o, !fused));
+    else PMFCHK(launch_layer_grad(c, o, !fused));
+  }
   return 0;
 }
 
