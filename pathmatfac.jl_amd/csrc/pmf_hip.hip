@@ -1386,22 +1386,18 @@ template <int KB, int NW, int RBW>
 static int launch_fused_t(pmf_ctx *c, const FusedArgs &a, int grid, bool batch, bool mixed) {
   using Cfg = FusedCfg<KB, NW, RBW>;
   const size_t lds = Cfg::lds_bytes + (batch ? Cfg::lds_batch_extra : 0);
-  const bool full = a.want_gx && a.want_gy && a.dbg == 0;
+  // gradient mode (compile-time in the kernel): 0 both, 1 grad(X) only, 2 grad(Y) only, 3 run-time flags
+  const int gm = a.dbg != 0 ? 3 : (a.want_gx && a.want_gy ? 0 : (a.want_gx ? 1 : (a.want_gy ? 2 : 3)));
   void (*kern)(const FusedArgs) = nullptr;
   const int bmode = !batch ? 0 : (a.btd ? 1 : 2);
-#define PMF_PICK(BM, MX, FU) pmf_fused_kernel<KB, NW, RBW, BM, MX, FU>
-  if (full) {
-    if (bmode == 0) kern = mixed ? PMF_PICK(0, true, true) : PMF_PICK(0, false, true);
-    else if (bmode == 1) kern = mixed ? PMF_PICK(1, true, true) : PMF_PICK(1, false, true);
-    else kern = mixed ? PMF_PICK(2, true, true) : PMF_PICK(2, false, true);
-  } else {
-    if (bmode == 0) kern = mixed ? PMF_PICK(0, true, false) : PMF_PICK(0, false, false);
-    else if (bmode == 1) kern = mixed ? PMF_PICK(1, true, false) : PMF_PICK(1, false, false);
-    else kern = mixed ? PMF_PICK(2, true, false) : PMF_PICK(2, false, false);
-  }
-#undef PMF_PICK
-  static bool attr_set[12] = {false, false, false, false, false, false, false, false, false, false, false, false};
-  const int vi = (full ? 6 : 0) + bmode * 2 + (mixed ? 1 : 0);
+#define PMF_PICK_G(BM, MX) (gm == 0 ? pmf_fused_kernel<KB, NW, RBW, BM, MX, 0> : gm == 1 ? pmf_fused_kernel<KB, NW, RBW, BM, MX, 1> : \
+                            gm == 2 ? pmf_fused_kernel<KB, NW, RBW, BM, MX, 2> : pmf_fused_kernel<KB, NW, RBW, BM, MX, 3>)
+  if (bmode == 0) kern = mixed ? PMF_PICK_G(0, true) : PMF_PICK_G(0, false);
+  else if (bmode == 1) kern = mixed ? PMF_PICK_G(1, true) : PMF_PICK_G(1, false);
+  else kern = mixed ? PMF_PICK_G(2, true) : PMF_PICK_G(2, false);
+#undef PMF_PICK_G
+  static bool attr_set[24] = {};
+  const int vi = gm * 6 + bmode * 2 + (mixed ? 1 : 0);
   if (!attr_set[vi]) {
     HIPCHK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_set[vi] = true;

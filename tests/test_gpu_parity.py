@@ -113,6 +113,23 @@ def test_loss_and_factor_gradients_match_oracle(ctx, name):
     assert rel_err(g["Y"], gd["Y"]) <= GRAD_TOL, rel_err(g["Y"], gd["Y"])
 
 
+@pytest.mark.parametrize("which", ["X", "Y"])
+@pytest.mark.parametrize("name", ["ragged_k64_nan", "mixed_batch_nan", "k100_4wave", "c1_500x200_k4"])
+def test_single_factor_gradient_matches_oracle(ctx, name, which):
+    """grad(X)-only launches (transform: Y fixed, transform.jl) and grad(Y)-only launches are separate compile-time
+    variants of the fused kernel (no GEMM3 / no GEMM2): each against the oracle."""
+    p = make_problem(seed=13, **CASES[name])
+    to_context(p, ctx)
+    flags = dict(update_X=which == "X", update_Y=which == "Y")
+    loss, g = grads_of(ctx, p, **flags)
+    m = to_oracle(p)
+    m.m.n_xreg = 0
+    m.m.n_yreg = 0
+    _, go = m.loss_and_grads(**flags)
+    assert abs(loss - go["data_loss"]) <= LOSS_RTOL * abs(go["data_loss"]) + 1e-6
+    assert rel_err(g[which], go[which]) <= GRAD_TOL
+
+
 @pytest.mark.parametrize("name", ["mixed_batch_nan", "poisson_batch", "ragged_k32"])
 def test_layer_gradients_match_oracle(ctx, name):
     kw = dict(CASES[name])
