@@ -505,7 +505,7 @@ __global__ __launch_bounds__(64) void k_layer_grad(const LayerGradArgs a) {
   if (tid == 0 && a.loss_partial) a.loss_partial[(int64_t)blockIdx.y * gridDim.x + blockIdx.x] = s;
 }
 
-// Same thread-per-column structure as k_layer_grad; called a handful of times per fit, not per epoch.
+// Called a handful of times per fit, not per epoch.
 // ------------------------------------------------------------------------------------------------
 struct StatsArgs {
   const float *D, *X, *Y;
@@ -520,10 +520,15 @@ struct StatsArgs {
   int64_t val_off[PMF_MAXV];
 };
 
+// Same structure as k_layer_grad<KB>: one wave per workgroup, thread = column, Y column in registers, four rows of X
+// at a time through LDS (broadcast 16-B reads, no barrier), per-(batch, column) sums in LDS.
+template <int KB>
 __global__ __launch_bounds__(64) void k_stats(const StatsArgs a) {
+  constexpr int Kp = 32 * KB;
+  constexpr int RG = 4;
   extern __shared__ __attribute__((aligned(16))) char smem_st[];
-  float *xs = reinterpret_cast<float *>(smem_st);
-  float *bacc = xs + a.Kp;  // [2][max_nb][64]
+  float *xs = reinterpret_cast<float *>(smem_st);   // [RG][Kp]
+  float *bacc = xs + RG * Kp;                        // [2][max_nb][64]
   const int tid = threadIdx.x;
   const int64_t j = blockIdx.x * 64 + tid;
   const bool col_ok = j < a.N;
@@ -538,37 +543,63 @@ __global__ __launch_bounds__(64) void k_stats(const StatsArgs a) {
   const ViewDesc vd = a.views[v >= 0 ? v : 0];
   for (int e = tid; e < 2 * a.max_nb * 64; e += 64) bacc[e] = 0.f;
   float sn = 0.f, s1 = 0.f, s2 = 0.f, se = 0.f, sg = 0.f;
-  const float *y = a.Y + jc * a.Kp;
-  for (int64_t i = r0; i < r1; ++i) {
-    float acc = 0.f;
+  float4 yr[Kp / 4];
+  {
+    const float4 *y4 = reinterpret_cast<const float4 *>(a.Y + jc * Kp);
+#pragma unroll
+    for (int q = 0; q < Kp / 4; ++q) yr[q] = y4[q];
+  }
+  for (int64_t ib = r0; ib < r1; ib += RG) {
     if (a.use_factors) {
-      __syncthreads();
-      for (int k = tid; k < a.Kp; k += 64) xs[k] = a.X[i * a.Kp + k];
-      __syncthreads();
-      for (int k = 0; k < a.K; ++k) acc = fmaf(xs[k], y[k], acc);
-    }
-    float dl = 1.f, th = 0.f;
-    int b = -1;
-    if (v >= 0) {
-      b = a.bor[(int64_t)v * a.M + i];
-      if (b >= 0) {
-        const float2 dt = a.btab[vd.tab_off + (jc - vd.c0) * vd.nb + b];
-        dl = dt.x;
-        th = dt.y;
+      __builtin_amdgcn_wave_barrier();
+      for (int e4 = tid; e4 < RG * Kp / 4; e4 += 64) {
+        const int rr = (e4 * 4) / Kp;
+        const int64_t i = ib + rr < r1 ? ib + rr : r1 - 1;
+        reinterpret_cast<float4 *>(xs)[e4] = reinterpret_cast<const float4 *>(a.X + i * Kp)[(e4 * 4 % Kp) / 4];
       }
+      __builtin_amdgcn_wave_barrier();
     }
-    const float yv = a.D[pmf_d_off(i, jc, a.nRB)];
-    if (!(fabsf(yv) <= 3.402823466e38f)) continue;
-    const float z = fmaf(acc * cp.x, dl, cp.y + th);
-    float pred, g;
-    if (kind == PMF_NOISE_NORMAL) { pred = z; g = cp.z * (z - yv); }
-    else if (kind == PMF_NOISE_BERNOULLI) { pred = 1.f / (1.f + __expf(-z)); g = cp.z * (pred - yv); }
-    else { pred = __expf(z); g = cp.z * (pred - yv); }
-    const float r = pred - yv;
-    sn += 1.f; s1 += yv; s2 += yv * yv; se += r * r; sg += g * g;
-    if (b >= 0) {
-      bacc[b * 64 + tid] += 1.f;
-      bacc[(a.max_nb + b) * 64 + tid] += r * r;
+#pragma unroll
+    for (int rr = 0; rr < RG; ++rr) {
+      const int64_t i = ib + rr;
+      if (i >= r1) break;
+      float acc = 0.f;
+      if (a.use_factors) {
+        const float4 *x4 = reinterpret_cast<const float4 *>(xs + rr * Kp);
+        float acc0 = 0.f, acc1 = 0.f;
+#pragma unroll
+        for (int q = 0; q < Kp / 4; ++q) {
+          const float4 xv = x4[q];
+          acc0 = fmaf(xv.x, yr[q].x, acc0);
+          acc1 = fmaf(xv.y, yr[q].y, acc1);
+          acc0 = fmaf(xv.z, yr[q].z, acc0);
+          acc1 = fmaf(xv.w, yr[q].w, acc1);
+        }
+        acc = acc0 + acc1;
+      }
+      float dl = 1.f, th = 0.f;
+      int b = -1;
+      if (v >= 0) {
+        b = a.bor[(int64_t)v * a.M + i];
+        if (b >= 0) {
+          const float2 dt = a.btab[vd.tab_off + (jc - vd.c0) * vd.nb + b];
+          dl = dt.x;
+          th = dt.y;
+        }
+      }
+      const float yv = a.D[pmf_d_off(i, jc, a.nRB)];
+      if (!(fabsf(yv) <= 3.402823466e38f)) continue;
+      const float z = fmaf(acc * cp.x, dl, cp.y + th);
+      float pred, g;
+      if (kind == PMF_NOISE_NORMAL) { pred = z; g = cp.z * (z - yv); }
+      else if (kind == PMF_NOISE_BERNOULLI) { pred = 1.f / (1.f + __expf(-z)); g = cp.z * (pred - yv); }
+      else { pred = __expf(z); g = cp.z * (pred - yv); }
+      const float r = pred - yv;
+      sn += 1.f; s1 += yv; s2 += yv * yv; se += r * r; sg += g * g;
+      if (b >= 0) {
+        bacc[b * 64 + tid] += 1.f;
+        bacc[(a.max_nb + b) * 64 + tid] += r * r;
+      }
     }
   }
   if (col_ok) {
@@ -1848,13 +1879,21 @@ extern "C" int pmf_stats(pmf_ctx *c, int use_factors, float *col_n, float *col_s
   }
   a.max_nb = max_nb;
   const int gx = nblocks(c->N, 64);
-  int64_t gy = std::max<int64_t>(1, std::min<int64_t>((8ll * c->n_cu + gx - 1) / gx, (c->M + 63) / 64));
+  int64_t gy = std::max<int64_t>(1, std::min<int64_t>((32ll * c->n_cu + gx - 1) / gx, (c->M + 255) / 256));
   a.rows_per_block = (int)((c->M + gy - 1) / gy);
   gy = (c->M + a.rows_per_block - 1) / a.rows_per_block;
-  const size_t lds = sizeof(float) * (size_t)(c->Kp + 2 * max_nb * 64);
+  const size_t lds = sizeof(float) * (size_t)(4 * c->Kp + 2 * max_nb * 64);
   if (lds > 160 * 1024) return pmf_fail("too many row batches per view (%d) for the statistics kernel", max_nb);
-  HIPCHK(hipFuncSetAttribute((const void *)k_stats, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL(k_stats, dim3(gx, (unsigned)gy), dim3(64), lds, c->stream, a);
+  void (*kst)(const StatsArgs) = nullptr;
+  switch (c->KB) {
+    case 1: kst = k_stats<1>; break;
+    case 2: kst = k_stats<2>; break;
+    case 3: kst = k_stats<3>; break;
+    case 4: kst = k_stats<4>; break;
+    default: return pmf_fail("unsupported KB=%d", c->KB);
+  }
+  HIPCHK(hipFuncSetAttribute((const void *)kst, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(kst, dim3(gx, (unsigned)gy), dim3(64), lds, c->stream, a);
   HIPCHK(hipGetLastError());
   HIPCHK(hipStreamSynchronize(c->stream));
   float *outs[5] = {col_n, col_sum, col_sumsq, col_sqerr, col_ssq_grad};
