@@ -32,3 +32,19 @@ def test_missing_library_fails_loudly(pkg, tmp_path):
     import pytest
     with pytest.raises(pkg.PMFError):
         pkg._lib.load_library(tmp_path / "nope.so")
+
+
+def test_plain_c_host_compiles_and_links(tmp_path):
+    """examples/fit_c.c uses the boundary from C alone (no Python, no torch): it must compile against the header and
+    link against the library (running it needs the GPU: tests/test_gpu_host.py)."""
+    import shutil
+    import subprocess
+    if shutil.which("gcc") is None:
+        import pytest
+        pytest.skip("gcc not available")
+    exe = tmp_path / "fit_c"
+    cmd = ["gcc", "-O2", "-Wall", "-Werror", f"-I{ROOT / 'include'}", str(ROOT / "examples" / "fit_c.c"),
+           f"-L{ROOT / 'pathmatfac.jl_amd'}", "-lpmf_hip", f"-Wl,-rpath,{ROOT / 'pathmatfac.jl_amd'}", "-lm", "-o", str(exe)]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert exe.exists()

@@ -133,3 +133,19 @@ def test_transform_shapes_and_embedding(pkg):
     # with exact low-rank data the embedding recovers the generating X (unregularized least squares on 30 columns)
     assert rel_err(result.matfac.X, Xn) < 5e-2
     model.release_device()
+
+
+def test_plain_c_host_runs(tmp_path):
+    """The C-ABI boundary driven from plain C (examples/fit_c.c): marshal -> pmf_fit -> unmarshal, loss decreases."""
+    import shutil
+    import subprocess
+    from pathlib import Path
+    root = Path(__file__).resolve().parent.parent
+    if shutil.which("gcc") is None:
+        pytest.skip("gcc not available")
+    exe = tmp_path / "fit_c"
+    subprocess.run(["gcc", "-O2", f"-I{root / 'include'}", str(root / "examples" / "fit_c.c"), f"-L{root / 'pathmatfac.jl_amd'}",
+                    "-lpmf_hip", f"-Wl,-rpath,{root / 'pathmatfac.jl_amd'}", "-lm", "-o", str(exe)], check=True)
+    r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, (r.stdout, r.stderr)
+    assert "term_code" in r.stdout
