@@ -1609,14 +1609,15 @@ static int launch_layer_grad(pmf_ctx *c, const pmf_fit_opts *o, bool with_loss) 
 }
 
 // Layer-parameter gradients through the MFMA layer pass (its own loss only in layer-only epochs); K <= 64 and <= 15 batches per view, otherwise the
-// VALU kernel above (PMF_LAYER_OLD=1 forces it, for comparison).
+// VALU kernel above (PMF_LAYER_OLD=1 forces it, for comparison).  K <= 128; views with <= 15 batches.
 static bool layer_pass_eligible(pmf_ctx *c) {
   const char *e = getenv("PMF_LAYER_OLD");
   if (e && atoi(e) == 1) return false;
-  return c->KB <= 2 && (c->n_bv == 0 || c->btd_ok);
+  return c->KB <= 4 && (c->n_bv == 0 || c->btd_ok);
 }
 static int launch_layer_pass(pmf_ctx *c, const pmf_fit_opts *o, bool with_loss) {
-  const int64_t n_ct = (c->N + PMF_BN - 1) / PMF_BN, n_rp = (c->M + 255) / 256;
+  const int lnw = c->KB <= 2 ? 8 : 4;   // waves per workgroup of the layer pass
+  const int64_t n_ct = (c->N + PMF_BN - 1) / PMF_BN, n_rp = (c->M + 32 * lnw - 1) / (32 * lnw);
   const int64_t n_seg = (n_ct + PMF_LS - 1) / PMF_LS;
   int64_t R = std::max<int64_t>(1, std::min<int64_t>(n_rp, (4ll * c->n_cu + n_seg - 1) / n_seg));
   const int grid = (int)std::min<int64_t>(n_seg * R, c->n_cu);
@@ -1639,10 +1640,14 @@ static int launch_layer_pass(pmf_ctx *c, const pmf_fit_opts *o, bool with_loss) 
   a.M = c->M; a.N = c->N; a.n_bv = c->n_bv; a.n_ct = (int)n_ct; a.n_rp = (int)n_rp; a.n_seg = (int)n_seg; a.R = (int)R;
   void (*kern)(const LayerPassArgs) = nullptr;
   size_t lds = 0;
-  if (c->KB == 1) { kern = c->mixed ? pmf_layer_kernel<1, true> : pmf_layer_kernel<1, false>; lds = LayerCfg<1>::lds_bytes; }
-  else { kern = c->mixed ? pmf_layer_kernel<2, true> : pmf_layer_kernel<2, false>; lds = LayerCfg<2>::lds_bytes; }
+  switch (c->KB) {
+    case 1: kern = c->mixed ? pmf_layer_kernel<1, 8, true> : pmf_layer_kernel<1, 8, false>; lds = LayerCfg<1, 8>::lds_bytes; break;
+    case 2: kern = c->mixed ? pmf_layer_kernel<2, 8, true> : pmf_layer_kernel<2, 8, false>; lds = LayerCfg<2, 8>::lds_bytes; break;
+    case 3: kern = c->mixed ? pmf_layer_kernel<3, 4, true> : pmf_layer_kernel<3, 4, false>; lds = LayerCfg<3, 4>::lds_bytes; break;
+    default: kern = c->mixed ? pmf_layer_kernel<4, 4, true> : pmf_layer_kernel<4, 4, false>; lds = LayerCfg<4, 4>::lds_bytes; break;
+  }
   HIPCHK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, c->stream, a);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * lnw), lds, c->stream, a);
   HIPCHK(hipGetLastError());
   LayerMapArgs m;
   memset(&m, 0, sizeof(m));
