@@ -1616,7 +1616,8 @@ static bool layer_pass_eligible(pmf_ctx *c) {
   return c->KB <= 4 && (c->n_bv == 0 || c->btd_ok);
 }
 static int launch_layer_pass(pmf_ctx *c, const pmf_fit_opts *o, bool with_loss) {
-  const int lnw = c->KB <= 2 ? 8 : 4;   // waves per workgroup of the layer pass
+  const char *lnwenv = getenv("PMF_LAYER_NW");
+  const int lnw = (c->KB <= 2 && !(lnwenv && atoi(lnwenv) == 4)) ? 8 : 4;   // waves per workgroup of the layer pass
   const int64_t n_ct = (c->N + PMF_BN - 1) / PMF_BN, n_rp = (c->M + 32 * lnw - 1) / (32 * lnw);
   const int64_t n_seg = (n_ct + PMF_LS - 1) / PMF_LS;
   int64_t R = std::max<int64_t>(1, std::min<int64_t>(n_rp, (4ll * c->n_cu + n_seg - 1) / n_seg));
@@ -1642,7 +1643,10 @@ static int launch_layer_pass(pmf_ctx *c, const pmf_fit_opts *o, bool with_loss) 
   size_t lds = 0;
   switch (c->KB) {
     case 1: kern = c->mixed ? pmf_layer_kernel<1, 8, true> : pmf_layer_kernel<1, 8, false>; lds = LayerCfg<1, 8>::lds_bytes; break;
-    case 2: kern = c->mixed ? pmf_layer_kernel<2, 8, true> : pmf_layer_kernel<2, 8, false>; lds = LayerCfg<2, 8>::lds_bytes; break;
+    case 2:
+      if (lnw == 8) { kern = c->mixed ? pmf_layer_kernel<2, 8, true> : pmf_layer_kernel<2, 8, false>; lds = LayerCfg<2, 8>::lds_bytes; }
+      else { kern = c->mixed ? pmf_layer_kernel<2, 4, true> : pmf_layer_kernel<2, 4, false>; lds = LayerCfg<2, 4>::lds_bytes; }
+      break;
     case 3: kern = c->mixed ? pmf_layer_kernel<3, 4, true> : pmf_layer_kernel<3, 4, false>; lds = LayerCfg<3, 4>::lds_bytes; break;
     default: kern = c->mixed ? pmf_layer_kernel<4, 4, true> : pmf_layer_kernel<4, 4, false>; lds = LayerCfg<4, 4>::lds_bytes; break;
   }
