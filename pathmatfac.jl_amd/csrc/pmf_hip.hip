@@ -1418,14 +1418,16 @@ static int launch_fused_t(pmf_ctx *c, const FusedArgs &a, int grid, bool batch, 
   using Cfg = FusedCfg<KB, NW, RBW>;
   const size_t lds = Cfg::lds_bytes + (batch ? Cfg::lds_batch_extra : 0);
   // gradient mode (compile-time in the kernel): 0 both, 1 grad(X) only, 2 grad(Y) only, 3 run-time flags
-  const int gm = a.dbg != 0 ? 3 : (a.want_gx && a.want_gy ? 0 : (a.want_gx ? 1 : (a.want_gy ? 2 : 3)));
+  int gm = a.dbg != 0 ? 3 : (a.want_gx && a.want_gy ? 0 : (a.want_gx ? 1 : (a.want_gy ? 2 : 3)));
   void (*kern)(const FusedArgs) = nullptr;
   const int bmode = !batch ? 0 : (a.btd ? 1 : 2);
+  if (bmode == 2 && gm != 0) gm = 3;   // the gather fallback (> 15 batches per view) has no single-gradient variants
 #define PMF_PICK_G(BM, MX) (gm == 0 ? pmf_fused_kernel<KB, NW, RBW, BM, MX, 0> : gm == 1 ? pmf_fused_kernel<KB, NW, RBW, BM, MX, 1> : \
                             gm == 2 ? pmf_fused_kernel<KB, NW, RBW, BM, MX, 2> : pmf_fused_kernel<KB, NW, RBW, BM, MX, 3>)
   if (bmode == 0) kern = mixed ? PMF_PICK_G(0, true) : PMF_PICK_G(0, false);
   else if (bmode == 1) kern = mixed ? PMF_PICK_G(1, true) : PMF_PICK_G(1, false);
-  else kern = mixed ? PMF_PICK_G(2, true) : PMF_PICK_G(2, false);
+  else if (gm == 0) kern = mixed ? pmf_fused_kernel<KB, NW, RBW, 2, true, 0> : pmf_fused_kernel<KB, NW, RBW, 2, false, 0>;
+  else kern = mixed ? pmf_fused_kernel<KB, NW, RBW, 2, true, 3> : pmf_fused_kernel<KB, NW, RBW, 2, false, 3>;
 #undef PMF_PICK_G
   static bool attr_set[24] = {};
   const int vi = gm * 6 + bmode * 2 + (mixed ? 1 : 0);
@@ -1462,12 +1464,13 @@ static int launch_fused(pmf_ctx *c, bool want_gx, bool want_gy) {
   // variant: waves per workgroup NW and 32-row blocks per wave RBW (the workgroup's row panel is 32*NW*RBW rows)
   //   K <= 32 : 8 waves x 2 row blocks (per-tile overheads amortised over twice the MFMA work; x 1 with batch layers)
   //   K <= 64 : 8 waves x 1          K <= 128 : 4 waves x 1 (one wave per SIMD, whole register file)
-  // PMF_RBW=1|2 overrides RBW for K <= 64 (K <= 64 with RBW = 2 runs 4 waves x 2: development comparison)
+  // PMF_RBW=1 forces one row block for K <= 32 (development comparison; 4 waves x 2 blocks at K = 64 measured 3 % slower
+  // than 8 x 1 and was removed)
   const char *rbwenv = getenv("PMF_RBW");
   // (the batch-layer epilogue of two row blocks does not fit the 256-register budget: RBW = 2 spills and is 1.5x slower)
-  int NW = c->KB <= 2 ? 8 : 4, RBW = (c->KB == 1 && c->n_bv == 0) ? 2 : 1;
-  if (rbwenv && c->KB <= 2) RBW = atoi(rbwenv) == 2 ? 2 : 1;
-  if (c->KB == 2 && RBW == 2) NW = 4;
+  const int NW = c->KB <= 2 ? 8 : 4;
+  int RBW = (c->KB == 1 && c->n_bv == 0) ? 2 : 1;
+  if (rbwenv && c->KB == 1 && atoi(rbwenv) == 1) RBW = 1;
   const int BM = 32 * NW * RBW;
   const int64_t n_rp = (c->M + BM - 1) / BM;
   const int64_t n_ct = (c->N + PMF_BN - 1) / PMF_BN;  // column tiles
@@ -1545,7 +1548,6 @@ static int launch_fused(pmf_ctx *c, bool want_gx, bool want_gy) {
     case 11: rc = launch_fused_t<1, 8, 1>(c, a, grid, batch, c->mixed); break;
     case 12: rc = launch_fused_t<1, 8, 2>(c, a, grid, batch, c->mixed); break;
     case 21: rc = launch_fused_t<2, 8, 1>(c, a, grid, batch, c->mixed); break;
-    case 22: rc = launch_fused_t<2, 4, 2>(c, a, grid, batch, c->mixed); break;
     case 31: rc = launch_fused_t<3, 4, 1>(c, a, grid, batch, c->mixed); break;
     case 41: rc = launch_fused_t<4, 4, 1>(c, a, grid, batch, c->mixed); break;
     default: return pmf_fail("unsupported KB=%d", c->KB);
