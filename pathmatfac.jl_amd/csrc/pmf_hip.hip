@@ -75,6 +75,7 @@ struct pmf_ctx {
   std::vector<int64_t> bvb_off;  // per view offset into the flat per-(view,batch) arrays
   int32_t *bor = nullptr;
   float2 *btab = nullptr;
+  bool views_dirty = true;        // `views` changed since the last upload
   ViewDesc *d_views = nullptr;    // device copy of `views` for the fused kernel's global-gather fallback
   float2 *LG = nullptr;           // [N][16] {S_G, S_Q} of the layer pass (pmf_layers.hip.inc)
   int64_t LG_cap = 0;
@@ -759,7 +760,7 @@ extern "C" int pmf_destroy(pmf_ctx *c) {
   for (auto &b : c->P) param_free(b);
   if (c->own_D) dev_free(&c->D);
   dev_free(&c->tflags);
-  dev_free(&c->bor); dev_free(&c->btab); dev_free(&c->btd); c->btd_cap = 0; c->btd_ok = false; dev_free(&c->LG); c->LG_cap = 0; dev_free(&c->d_views); dev_free(&c->d_val_view);
+  dev_free(&c->bor); dev_free(&c->btab); dev_free(&c->btd); c->btd_cap = 0; c->btd_ok = false; dev_free(&c->LG); c->LG_cap = 0; dev_free(&c->d_views); c->views_dirty = true; dev_free(&c->d_val_view);
   dev_free(&c->colmeta); dev_free(&c->colw); dev_free(&c->colp);
   dev_free(&c->ard_alpha); dev_free(&c->ard_beta);
   dev_free(&c->wg_begin); dev_free(&c->c_off); dev_free(&c->c_idx); dev_free(&c->gy_slabs); dev_free(&c->loss_partial); dev_free(&c->reg_partial); dev_free(&c->d_loss);
@@ -803,9 +804,10 @@ static int data_shape_changed(pmf_ctx *c, int64_t M, int64_t N) {
   PMFCHK(param_alloc(c->P[3], N));
   c->n_bv = 0;
   c->views.clear();
+  c->views_dirty = true;
   c->val_off.clear();
   c->bvb_off.clear();
-  dev_free(&c->bor); dev_free(&c->btab); dev_free(&c->btd); c->btd_cap = 0; c->btd_ok = false; dev_free(&c->LG); c->LG_cap = 0; dev_free(&c->d_views); dev_free(&c->d_val_view);
+  dev_free(&c->bor); dev_free(&c->btab); dev_free(&c->btd); c->btd_cap = 0; c->btd_ok = false; dev_free(&c->LG); c->LG_cap = 0; dev_free(&c->d_views); c->views_dirty = true; dev_free(&c->d_val_view);
   PMFCHK(dev_alloc(&c->colmeta, (size_t)N));
   PMFCHK(dev_alloc(&c->colw, (size_t)N));
   PMFCHK(dev_alloc(&c->colp, (size_t)N));
@@ -939,6 +941,7 @@ extern "C" int pmf_set_n_batch_views(pmf_ctx *c, int n) {
   if (c->N == 0) return pmf_fail("data not set");
   c->n_bv = n;
   c->views.assign((size_t)n, ViewDesc{0, 0, 0, 0, 0});
+  c->views_dirty = true;
   c->val_off.assign((size_t)n + 1, 0);
   c->bvb_off.assign((size_t)n + 1, 0);
   param_free(c->P[4]);
@@ -968,6 +971,7 @@ extern "C" int pmf_set_batch_view(pmf_ctx *c, int v, int64_t s1, int64_t e1, int
   c->views[v].c0 = s1 - 1;
   c->views[v].c1 = e1;
   c->views[v].nb = nb;
+  c->views_dirty = true;
   HIPCHK(hipMemcpy(c->bor + (int64_t)v * c->M, batch_of_row, sizeof(int32_t) * (size_t)c->M, hipMemcpyHostToDevice));
   if (!same_shape) {
     // (re)compute offsets for views >= v and reallocate the flat arrays once the last view is known
@@ -1249,9 +1253,12 @@ static int prepare(pmf_ctx *c) {
   HIPCHK(hipGetLastError());
   c->btd_ok = false;
   if (c->n_bv > 0) {
-    PMFCHK(dev_alloc(&c->d_views, (size_t)PMF_MAXV, false));
-    HIPCHK(hipMemcpyAsync(c->d_views, c->views.data(), sizeof(ViewDesc) * (size_t)c->n_bv, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
+    if (!c->d_views) PMFCHK(dev_alloc(&c->d_views, (size_t)PMF_MAXV, false));   // (prepare() runs every layer epoch: no re-allocation)
+    if (c->views_dirty) {
+      HIPCHK(hipMemcpyAsync(c->d_views, c->views.data(), sizeof(ViewDesc) * (size_t)c->n_bv, hipMemcpyHostToDevice, c->stream));
+      HIPCHK(hipStreamSynchronize(c->stream));
+      c->views_dirty = false;
+    }
     int nb_max = 0;
     for (int v = 0; v < c->n_bv; ++v) nb_max = std::max(nb_max, (int)c->views[v].nb);
     if (nb_max <= 15) {
