@@ -207,6 +207,18 @@ int pmf_forward(pmf_ctx *ctx, float *Z_host);
 int pmf_stats(pmf_ctx *ctx, int use_factors, float *col_n, float *col_sum, float *col_sumsq, float *col_sqerr,
               float *col_ssq_grad, float *batch_count, float *batch_sqerr);
 
+/* Arithmetic of the three matrix products of the fused data pass (no reference counterpart: the reference computes
+ * in Float32 on the GPU, src/fit.jl:24 via MatFac):
+ *   PMF_PREC_F32    (default) exact f32 MFMA, v_mfma_f32_32x32x2_f32
+ *   PMF_PREC_BF16X3 split-bf16: every f32 operand as a bf16 hi/lo pair, three bf16 MFMAs per product, f32 accumulation;
+ *                   ~4e-6 of max|Z| per product instead of 2e-7.  Used where a kernel variant exists (32 < K <= 64,
+ *                   no batch layers, X and Y both updating); every other launch silently stays exact.
+ * pmf_get_precision also reports how many fused launches of this context took the split-bf16 kernel. */
+#define PMF_PREC_F32 0
+#define PMF_PREC_BF16X3 1
+int pmf_set_precision(pmf_ctx *ctx, int mode);
+int pmf_get_precision(pmf_ctx *ctx, int *mode, int64_t *split_launches);
+
 /* per-launch timing of the fused data-pass kernel (HIP events on the library's stream): mean milliseconds and
  * number of launches since the last reset */
 int pmf_kernel_time(pmf_ctx *ctx, double *mean_ms, int64_t *launches, int reset);

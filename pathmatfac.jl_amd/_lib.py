@@ -47,6 +47,7 @@ EXPORTS = [
     "pmf_set_layer_regs", "pmf_set_optimizer", "pmf_set_lr", "pmf_get_lr", "pmf_reset_optimizer_state",
     "pmf_fit", "pmf_epoch_begin", "pmf_epoch_step_local", "pmf_epoch_step_shared", "pmf_epoch_loss",
     "pmf_grad_device_ptr", "pmf_get_grad", "pmf_forward", "pmf_stats", "pmf_kernel_time", "pmf_synth_data",
+    "pmf_set_precision", "pmf_get_precision",
 ]
 
 _lib = None
@@ -341,6 +342,15 @@ class Context:
             off += nb * nv
         out["batch_count"], out["batch_sqerr"] = cnt, sq
         return out
+
+    def set_precision(self, mode):
+        """'f32' (exact f32 MFMA, default) or 'bf16x3' (split-bf16 products where a kernel variant exists)."""
+        self._chk(self.lib.pmf_set_precision(self._h, {"f32": 0, "bf16x3": 1}[mode]))
+
+    def get_precision(self):
+        mode, n = C.c_int(0), C.c_int64(0)
+        self._chk(self.lib.pmf_get_precision(self._h, C.byref(mode), C.byref(n)))
+        return ("f32", "bf16x3")[mode.value], n.value
 
     def kernel_time(self, reset=False):
         ms, n = C.c_double(0), C.c_int64(0)

@@ -14,6 +14,7 @@
 
 #include "../../include/pmf_hip.h"
 #include "pmf_fused.hip.inc"
+#include "pmf_fused_sb.hip.inc"
 #include "pmf_layers.hip.inc"
 
 // ------------------------------------------------------------------------------------------------
@@ -107,6 +108,10 @@ struct pmf_ctx {
   int64_t kind_version = 0;
   float *gy_slabs = nullptr;      // [grid][Kp x N] private per-workgroup gY partial sums of the fused kernel
   size_t gy_slabs_cap = 0;        // floats
+  int precision = PMF_PREC_F32;   // products of the fused data pass: exact f32 MFMA, or split-bf16 (pmf_set_precision)
+  char *xsb = nullptr, *ysb = nullptr;   // split-bf16 operand images of X / sigma*Y, rebuilt every epoch (k_sb_split)
+  size_t xsb_cap = 0, ysb_cap = 0;       // bytes
+  int64_t sb_launches = 0;        // fused launches that took the split-bf16 kernel (pmf_get_precision)
   int64_t loss_cap = 0;
   int64_t n_macro = 0;
   double *reg_partial = nullptr;  // [4][REG_SLOTS]
@@ -749,6 +754,10 @@ extern "C" int pmf_create(int device, pmf_ctx **out) {
   HIPCHK(hipHostMalloc((void **)&c->h_loss, sizeof(double) * 8));
   HIPCHK(hipMalloc((void **)&c->reg_partial, sizeof(double) * 4 * REG_SLOTS));
   HIPCHK(hipMemset(c->reg_partial, 0, sizeof(double) * 4 * REG_SLOTS));
+  {
+    const char *pe = getenv("PMF_PRECISION");   // development / benchmark override of the default (exact f32)
+    if (pe && std::string(pe) == "bf16x3") c->precision = PMF_PREC_BF16X3;
+  }
   *out = c;
   return 0;
 }
@@ -763,12 +772,26 @@ extern "C" int pmf_destroy(pmf_ctx *c) {
   dev_free(&c->bor); dev_free(&c->btab); dev_free(&c->btd); c->btd_cap = 0; c->btd_ok = false; dev_free(&c->LG); c->LG_cap = 0; dev_free(&c->d_views); c->views_dirty = true; dev_free(&c->d_val_view);
   dev_free(&c->colmeta); dev_free(&c->colw); dev_free(&c->colp);
   dev_free(&c->ard_alpha); dev_free(&c->ard_beta);
-  dev_free(&c->wg_begin); dev_free(&c->c_off); dev_free(&c->c_idx); dev_free(&c->gy_slabs); dev_free(&c->loss_partial); dev_free(&c->reg_partial); dev_free(&c->d_loss);
+  dev_free(&c->wg_begin); dev_free(&c->c_off); dev_free(&c->c_idx); dev_free(&c->gy_slabs); dev_free(&c->xsb); dev_free(&c->ysb); dev_free(&c->loss_partial); dev_free(&c->reg_partial); dev_free(&c->d_loss);
   if (c->h_loss) (void)hipHostFree(c->h_loss);
   if (c->scratch) (void)hipFree(c->scratch);
   for (auto &e : c->ev_pool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
   if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
+  return 0;
+}
+
+extern "C" int pmf_set_precision(pmf_ctx *c, int mode) {
+  if (!c) return pmf_fail("null context");
+  if (mode != PMF_PREC_F32 && mode != PMF_PREC_BF16X3) return pmf_fail("unknown precision mode %d", mode);
+  c->precision = mode;
+  return 0;
+}
+
+extern "C" int pmf_get_precision(pmf_ctx *c, int *mode, int64_t *split_launches) {
+  if (!c) return pmf_fail("null context");
+  if (mode) *mode = c->precision;
+  if (split_launches) *split_launches = c->sb_launches;
   return 0;
 }
 
@@ -1536,6 +1559,19 @@ static int launch_fused(pmf_ctx *c, bool want_gx, bool want_gy) {
 #endif
   a.views = c->d_views;
   const bool batch = c->n_bv > 0;
+  // split-bf16 products (opt-in): first version covers 32 < K <= 64, no batch layers, both gradients
+  const bool sb = c->precision == PMF_PREC_BF16X3 && c->KB == 2 && !batch && want_gx && want_gy && a.dbg == 0;
+  if (sb) {
+    const size_t xb = (size_t)c->nRB * PMF_SB_BLK, yb = (size_t)n_ct * PMF_SB_BLK;
+    if (xb > c->xsb_cap) { dev_free(&c->xsb); c->xsb_cap = 0; PMFCHK(dev_alloc(&c->xsb, xb, false)); c->xsb_cap = xb; }
+    if (yb > c->ysb_cap) { dev_free(&c->ysb); c->ysb_cap = 0; PMFCHK(dev_alloc(&c->ysb, yb, false)); c->ysb_cap = yb; }
+    SbSplitArgs sx = {c->P[0].p, nullptr, c->M, c->nRB, c->xsb};
+    SbSplitArgs sy = {c->P[1].p, c->colp, c->N, n_ct, c->ysb};
+    k_sb_split<<<nblocks(c->nRB * 32 * 8, 256), 256, 0, c->stream>>>(sx);
+    k_sb_split<<<nblocks(n_ct * 32 * 8, 256), 256, 0, c->stream>>>(sy);
+    HIPCHK(hipGetLastError());
+    a.Xsb = c->xsb; a.Ysb = c->ysb;
+  }
   // timing events
   if (c->ev_used == c->ev_pool.size()) {
     if (c->ev_pool.size() >= 4096) {
@@ -1551,6 +1587,17 @@ static int launch_fused(pmf_ctx *c, bool want_gx, bool want_gy) {
   auto &ev = c->ev_pool[c->ev_used++];
   HIPCHK(hipEventRecord(ev.first, c->stream));
   int rc = 0;
+  if (sb) {
+    void (*kern)(const FusedArgs) = c->mixed ? pmf_fused_sb_kernel<true> : pmf_fused_sb_kernel<false>;
+    static bool sb_attr[2] = {false, false};
+    if (!sb_attr[c->mixed ? 1 : 0]) {
+      HIPCHK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SbCfg::lds_bytes));
+      sb_attr[c->mixed ? 1 : 0] = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), SbCfg::lds_bytes, c->stream, a);
+    HIPCHK(hipGetLastError());
+    c->sb_launches += 1;
+  } else
   switch (c->KB * 10 + RBW) {
     case 11: rc = launch_fused_t<1, 8, 1>(c, a, grid, batch, c->mixed); break;
     case 12: rc = launch_fused_t<1, 8, 2>(c, a, grid, batch, c->mixed); break;

@@ -14,6 +14,12 @@ __device__ inline void split(float a, __bf16 &hi, __bf16 &lo) {
   hi = (__bf16)a;
   lo = (__bf16)(a - (float)hi);
 }
+__device__ inline void split3(float a, __bf16 &hi, __bf16 &mid, __bf16 &lo) {
+  hi = (__bf16)a;
+  const float r = a - (float)hi;
+  mid = (__bf16)r;
+  lo = (__bf16)(r - (float)mid);
+}
 
 // A is [32][K] row-major, B is [32][K] (column n of the product is row n here: both operands are K-contiguous)
 __global__ void probe(const float *A, const float *B, float *Zf32, float *Zx3, float *Zx1, int terms) {
@@ -31,6 +37,22 @@ __global__ void probe(const float *A, const float *B, float *Zf32, float *Zx3, f
       split(B[l31 * K + 16 * s + 8 * h + q], x, y); bh[q] = x; bl[q] = y;
     }
     c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, c1, 0, 0, 0);
+    if (terms == 6) {
+      // three-way split, six of the nine partial products (what pmf_fused_sb_kernel's forward uses)
+      bf16x8 am, bm;
+      for (int q = 0; q < 8; ++q) {
+        __bf16 x, y, z;
+        split3(A[l31 * K + 16 * s + 8 * h + q], x, y, z); ah[q] = x; am[q] = y; al[q] = z;
+        split3(B[l31 * K + 16 * s + 8 * h + q], x, y, z); bh[q] = x; bm[q] = y; bl[q] = z;
+      }
+      c3 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, c3, 0, 0, 0);
+      c3 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, c3, 0, 0, 0);
+      c3 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm, c3, 0, 0, 0);
+      c3 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, c3, 0, 0, 0);
+      c3 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, c3, 0, 0, 0);
+      c3 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, c3, 0, 0, 0);
+      continue;
+    }
     c3 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, c3, 0, 0, 0);   // small terms first
     c3 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, c3, 0, 0, 0);
     if (terms >= 4) {
@@ -57,7 +79,7 @@ int main() {
   hipMalloc(&dA, A.size() * 4); hipMalloc(&dB, B.size() * 4); hipMalloc(&dZ, 3 * 1024 * 4);
   hipMemcpy(dA, A.data(), A.size() * 4, hipMemcpyHostToDevice);
   hipMemcpy(dB, B.data(), B.size() * 4, hipMemcpyHostToDevice);
-  for (int terms : {3, 4}) {
+  for (int terms : {3, 4, 6}) {
     probe<<<1, 64>>>(dA, dB, dZ, dZ + 1024, dZ + 2048, terms);
     std::vector<float> Z(3 * 1024);
     hipMemcpy(Z.data(), dZ, Z.size() * 4, hipMemcpyDeviceToHost);

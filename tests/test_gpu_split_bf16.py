@@ -1,0 +1,119 @@
+"""GPU parity tests of the opt-in split-bf16 ("bf16x3") data pass (pmf_set_precision, csrc/pmf_fused_sb.hip.inc)
+against the fp64 CPU oracle, through the C ABI, on the same seeded inputs as the exact-f32 tests.
+
+Tolerances: the same as tests/test_gpu_parity.py -- loss 2e-5 relative, gradients 2e-4 of max|gradient|, fitted factors
+2e-3 after 10 epochs.  The forward uses the six-term product (2.3e-7 of max|Z| on MI355X, the same as the exact f32 MFMA:
+scripts/bf16x3_probe.hip), the two gradient products the three-term one (4e-6).  A first version with a three-term
+forward failed these tests at 9e-4: the problems are evaluated at the generating factors, where G = w (Z - D) is 0.1 and
+|Z| is up to 45, so an error of 4e-6 |Z| in Z is 1e-3 of G.  Every test also checks that the split kernel really was the
+one launched (pmf_get_precision counts its launches): a silent fall back to the exact kernel would pass parity."""
+import numpy as np
+import pytest
+
+from problems import make_problem, rel_err, to_context, to_oracle
+from test_gpu_parity import FIT_TOL, GRAD_TOL, LOSS_RTOL, grads_of
+
+pytestmark = pytest.mark.gpu
+
+CASES = {
+    "ragged_k64_nan": dict(M=777, N=333, K=64, yreg="fsard", xreg="l2", nan_frac=0.1, weights=True, col_params=True),
+    "k33_small": dict(M=40, N=50, K=33, col_params=True),
+    "mixed_k48": dict(M=600, N=420, K=48, bernoulli_frac=0.25, poisson_frac=0.15, n_views=3, nan_frac=0.08, weights=True,
+                      col_params=True, scale=0.4),
+    # several row panels per workgroup and two column segments: the private gY slabs accumulate by read-modify-write
+    "many_panels_k40": dict(M=70000, N=600, K=40, xreg="l2", weights=True, col_params=True, scale=0.5),
+    "one_row_panel_many_cols": dict(M=33, N=1500, K=64, nan_frac=0.02),
+}
+
+
+@pytest.fixture()
+def sctx(ctx):
+    ctx.set_precision("bf16x3")
+    n0 = ctx.get_precision()[1]
+    yield ctx, n0
+    ctx.set_precision("f32")
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_split_bf16_loss_and_gradients_match_oracle(sctx, name):
+    ctx, n0 = sctx
+    p = make_problem(seed=11, **CASES[name])
+    to_context(p, ctx)
+    loss, g = grads_of(ctx, p, update_X=True, update_Y=True)
+    assert ctx.get_precision() == ("bf16x3", n0 + 1), "the split-bf16 kernel was not launched"
+    m = to_oracle(p)
+    m.m.n_xreg = 0
+    m.m.n_yreg = 0
+    _, gd = m.loss_and_grads(update_X=True, update_Y=True)
+    assert abs(loss - gd["data_loss"]) <= LOSS_RTOL * abs(gd["data_loss"]) + 1e-6, (loss, gd["data_loss"])
+    assert rel_err(g["X"], gd["X"]) <= GRAD_TOL, rel_err(g["X"], gd["X"])
+    assert rel_err(g["Y"], gd["Y"]) <= GRAD_TOL, rel_err(g["Y"], gd["Y"])
+
+
+@pytest.mark.parametrize("opt", ["adagrad", "adam"])
+def test_split_bf16_fit_trajectory_matches_oracle(sctx, opt):
+    ctx, n0 = sctx
+    p = make_problem(seed=13, random_init=True, **CASES["ragged_k64_nan"])
+    lr = 0.05 if opt == "adagrad" else 0.01
+    to_context(p, ctx)
+    ctx.set_optimizer(opt, lr=lr)
+    r = ctx.fit(update_X=True, update_Y=True, max_epochs=10, abs_tol=0, rel_tol=0)
+    assert ctx.get_precision()[1] == n0 + 10
+    m = to_oracle(p)
+    ro = m.fit(update_X=True, update_Y=True, opt=opt, lr=lr, max_epochs=10, abs_tol=0, rel_tol=0)
+    assert r["term_code"] == ro["term_code"] and r["epochs"] == ro["epochs"]
+    np.testing.assert_allclose(r["loss"], ro["loss"], rtol=5e-5)
+    X, Y = ctx.get_factors()
+    assert rel_err(X, m.X) <= FIT_TOL, rel_err(X, m.X)
+    assert rel_err(Y, m.Y) <= FIT_TOL, rel_err(Y, m.Y)
+
+
+def test_split_bf16_agrees_with_exact_kernel_at_config_size(sctx):
+    """20000 x 10000, K = 64 (BASELINE configs[1] shape at the headline K): loss and both gradients of the split-bf16
+    kernel against the exact-f32 kernel on the same device data, and gY bitwise reproducible run to run."""
+    ctx, n0 = sctx
+    M, N, K = 20000, 10000, 64
+    rng = np.random.default_rng(23)
+    ctx.set_data_device(None, M, N)
+    ctx.set_factors((rng.standard_normal((K, M)) * 0.3).astype(np.float32), (rng.standard_normal((K, N)) * 0.3).astype(np.float32))
+    ctx.set_col_params((rng.standard_normal(N) * 0.1).astype(np.float32), rng.standard_normal(N).astype(np.float32))
+    ctx.set_batch_views([])
+    ctx.set_noise([(1, N)], ["normal"], (0.5 + rng.random(N)).astype(np.float32))
+    ctx.synth_data(seed=5, noise=0.5, frac_nan=0.03)
+    o = ctx.make_opts(update_X=True, update_Y=True)
+
+    def run():
+        ctx.epoch_begin(o)
+        loss, _ = ctx.epoch_loss()
+        return loss, ctx.get_grad("X"), ctx.get_grad("Y")
+
+    l1, gx1, gy1 = run()
+    l2, _, gy2 = run()
+    assert ctx.get_precision()[1] == n0 + 2
+    assert l1 == l2 and np.array_equal(gy1, gy2)
+    ctx.set_precision("f32")
+    l0, gx0, gy0 = run()
+    assert ctx.get_precision()[1] == n0 + 2
+    assert abs(l1 - l0) <= LOSS_RTOL * abs(l0), (l1, l0)
+    assert rel_err(gx1, gx0) <= GRAD_TOL, rel_err(gx1, gx0)
+    assert rel_err(gy1, gy0) <= GRAD_TOL, rel_err(gy1, gy0)
+
+
+def test_split_bf16_falls_back_to_exact_kernel_outside_its_scope(sctx):
+    """K <= 32, K > 64, batch layers and single-gradient launches have no split-bf16 variant yet: they must run the
+    exact kernel (and say so through the launch counter), not fail."""
+    ctx, n0 = sctx
+    for case in (dict(M=301, N=143, K=32), dict(M=200, N=150, K=100),
+                 dict(M=420, N=260, K=64, n_views=2, batch_views=2, n_batches=8, col_params=True)):
+        p = make_problem(seed=11, **case)
+        to_context(p, ctx)
+        loss, g = grads_of(ctx, p, update_X=True, update_Y=True)
+        m = to_oracle(p)
+        m.m.n_xreg = 0
+        m.m.n_yreg = 0
+        _, gd = m.loss_and_grads(update_X=True, update_Y=True)
+        assert rel_err(g["Y"], gd["Y"]) <= GRAD_TOL
+    p = make_problem(seed=11, **CASES["ragged_k64_nan"])
+    to_context(p, ctx)
+    grads_of(ctx, p, update_X=True, update_Y=False)
+    assert ctx.get_precision()[1] == n0
