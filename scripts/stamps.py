@@ -24,7 +24,7 @@ buf = np.zeros(16 * 8 * 256, np.uint64)
 assert ctx.lib.pmf_debug_stamps(buf.ctypes.data_as(C.POINTER(C.c_ulonglong)), buf.size) == 0
 st = buf.reshape(-1, 16).astype(np.float64)
 st = st[st.sum(1) > 0]
-names = ["loop/B2 exit", "epilogue", "gY slab prefetch issue", "GEMM2", "GEMM3+slab wr", "stage_store", "B1 wait", "reduce+slab store",
+names = ["loop/B2 exit", "epilogue", "gY slab prefetch issue (split kernel: G split + image writes)", "GEMM2", "GEMM3+slab wr", "stage_store", "B1 wait", "reduce+slab store",
          "forward", "B2 wait", "(pre-flush)", "macro prologue/flush", "  Y/colp load issue", "  D load issue"]
 clk = np.median(st[:, 14] / st[:, 15]) * 100.0
 st = st[:, :14]

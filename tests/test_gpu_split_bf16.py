@@ -23,6 +23,9 @@ CASES = {
     # several row panels per workgroup and two column segments: the private gY slabs accumulate by read-modify-write
     "many_panels_k40": dict(M=70000, N=600, K=40, xreg="l2", weights=True, col_params=True, scale=0.5),
     "one_row_panel_many_cols": dict(M=33, N=1500, K=64, nan_frac=0.02),
+    # two-tile segments and more work items than workgroups: consecutive pieces of a workgroup re-read private-slab
+    # entries they stored a moment ago (the prefetch runs a tile ahead of the store)
+    "many_panels_two_tiles": dict(M=70000, N=40, K=64, weights=True, scale=0.5),
 }
 
 
