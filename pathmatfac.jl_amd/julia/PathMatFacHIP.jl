@@ -40,6 +40,13 @@ f32(a) = convert(Array{Float32}, a)
 starts(rs) = Int64[r.start for r in rs]
 stops(rs) = Int64[r.stop for r in rs]
 
+# Arithmetic of the data pass's matrix products (include/pmf_hip.h): :f32 = exact f32 MFMA (default),
+# :bf16x3 = split-bf16 products where a kernel variant exists (DESIGN.md 4.5).  No reference counterpart.
+function set_precision!(model, mode::Symbol)
+    code = mode == :f32 ? 0 : mode == :bf16x3 ? 1 : error("precision must be :f32 or :bf16x3")
+    chk(ccall((:pmf_set_precision, LIB[]), Cint, (Ptr{Cvoid}, Cint), context!(model), code))
+end
+
 function context!(model; device::Integer=0)
     ctx = get!(CTX, model) do
         p = Ref{Ptr{Cvoid}}(C_NULL)
