@@ -1515,6 +1515,10 @@ static int launch_fused(pmf_ctx *c, bool want_gx, bool want_gy) {
   const double a_cost = tiles_per_wg * 8e-6;
   const double b_cost = (double)grid0 * (double)c->Kp * (double)c->N * 4.0 / ((double)n_ct * 4e12);
   int64_t tiles_per_seg = (int64_t)std::llround(std::sqrt(a_cost / std::max(b_cost, 1e-12)));
+  {
+    const char *ts = getenv("PMF_TPS_SCALE");   // development: scale the model's segment length
+    if (ts) tiles_per_seg = (int64_t)std::llround((double)tiles_per_seg * atof(ts));
+  }
   tiles_per_seg = std::max<int64_t>(std::min<int64_t>(8, n_ct), std::min<int64_t>(tiles_per_seg, n_ct));
   // equal segments; the LAST one takes the remainder (it is longer, never tiny: every piece of work pays the fixed
   // prologue, so a 5-tile last segment once made one workgroup 20 % late)
@@ -1560,7 +1564,7 @@ static int launch_fused(pmf_ctx *c, bool want_gx, bool want_gy) {
   a.views = c->d_views;
   const bool batch = c->n_bv > 0;
   // split-bf16 products (opt-in): first version covers 32 < K <= 64, no batch layers, both gradients
-  const bool sb = c->precision == PMF_PREC_BF16X3 && c->KB == 2 && !batch && want_gx && want_gy && a.dbg == 0;
+  const bool sb = c->precision == PMF_PREC_BF16X3 && c->KB == 2 && !batch && want_gx && a.dbg == 0;
   if (sb) {
     const size_t xb = (size_t)c->nRB * PMF_SB_BLK, yb = (size_t)n_ct * PMF_SB_BLK;
     if (xb > c->xsb_cap) { dev_free(&c->xsb); c->xsb_cap = 0; PMFCHK(dev_alloc(&c->xsb, xb, false)); c->xsb_cap = xb; }
@@ -1588,11 +1592,13 @@ static int launch_fused(pmf_ctx *c, bool want_gx, bool want_gy) {
   HIPCHK(hipEventRecord(ev.first, c->stream));
   int rc = 0;
   if (sb) {
-    void (*kern)(const FusedArgs) = c->mixed ? pmf_fused_sb_kernel<true> : pmf_fused_sb_kernel<false>;
-    static bool sb_attr[2] = {false, false};
-    if (!sb_attr[c->mixed ? 1 : 0]) {
+    void (*kern)(const FusedArgs) = want_gy ? (c->mixed ? pmf_fused_sb_kernel<true, true> : pmf_fused_sb_kernel<false, true>)
+                                            : (c->mixed ? pmf_fused_sb_kernel<true, false> : pmf_fused_sb_kernel<false, false>);
+    static bool sb_attr[4] = {false, false, false, false};
+    const int vi = (want_gy ? 2 : 0) + (c->mixed ? 1 : 0);
+    if (!sb_attr[vi]) {
       HIPCHK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SbCfg::lds_bytes));
-      sb_attr[c->mixed ? 1 : 0] = true;
+      sb_attr[vi] = true;
     }
     hipLaunchKernelGGL(kern, dim3(grid), dim3(512), SbCfg::lds_bytes, c->stream, a);
     HIPCHK(hipGetLastError());

@@ -103,7 +103,7 @@ def test_split_bf16_agrees_with_exact_kernel_at_config_size(sctx):
 
 
 def test_split_bf16_falls_back_to_exact_kernel_outside_its_scope(sctx):
-    """K <= 32, K > 64, batch layers and single-gradient launches have no split-bf16 variant yet: they must run the
+    """K <= 32, K > 64, batch layers and grad(Y)-only launches have no split-bf16 variant yet: they must run the
     exact kernel (and say so through the launch counter), not fail."""
     ctx, n0 = sctx
     for case in (dict(M=301, N=143, K=32), dict(M=200, N=150, K=100),
@@ -118,5 +118,21 @@ def test_split_bf16_falls_back_to_exact_kernel_outside_its_scope(sctx):
         assert rel_err(g["Y"], gd["Y"]) <= GRAD_TOL
     p = make_problem(seed=11, **CASES["ragged_k64_nan"])
     to_context(p, ctx)
-    grads_of(ctx, p, update_X=True, update_Y=False)
+    grads_of(ctx, p, update_X=False, update_Y=True)
     assert ctx.get_precision()[1] == n0
+
+
+@pytest.mark.parametrize("name", ["ragged_k64_nan", "mixed_k48", "many_panels_k40"])
+def test_split_bf16_transform_mode_gradient_matches_oracle(sctx, name):
+    """grad(X)-only launches (transform: Y and the layers fixed, transform.jl) take the variant without GEMM3 / slabs."""
+    ctx, n0 = sctx
+    p = make_problem(seed=13, **CASES[name])
+    to_context(p, ctx)
+    loss, g = grads_of(ctx, p, update_X=True, update_Y=False)
+    assert ctx.get_precision()[1] == n0 + 1
+    m = to_oracle(p)
+    m.m.n_xreg = 0
+    m.m.n_yreg = 0
+    _, go = m.loss_and_grads(update_X=True, update_Y=False)
+    assert abs(loss - go["data_loss"]) <= LOSS_RTOL * abs(go["data_loss"]) + 1e-6
+    assert rel_err(g["X"], go["X"]) <= GRAD_TOL, rel_err(g["X"], go["X"])
