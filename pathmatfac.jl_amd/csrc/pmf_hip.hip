@@ -1564,7 +1564,7 @@ static int launch_fused(pmf_ctx *c, bool want_gx, bool want_gy) {
   a.views = c->d_views;
   const bool batch = c->n_bv > 0;
   // split-bf16 products (opt-in): first version covers 32 < K <= 64, no batch layers, both gradients
-  const bool sb = c->precision == PMF_PREC_BF16X3 && c->KB == 2 && !batch && want_gx && a.dbg == 0;
+  const bool sb = c->precision == PMF_PREC_BF16X3 && c->KB == 2 && !batch && (want_gx || want_gy) && a.dbg == 0;
   if (sb) {
     const size_t xb = (size_t)c->nRB * PMF_SB_BLK, yb = (size_t)n_ct * PMF_SB_BLK;
     if (xb > c->xsb_cap) { dev_free(&c->xsb); c->xsb_cap = 0; PMFCHK(dev_alloc(&c->xsb, xb, false)); c->xsb_cap = xb; }
@@ -1592,10 +1592,12 @@ static int launch_fused(pmf_ctx *c, bool want_gx, bool want_gy) {
   HIPCHK(hipEventRecord(ev.first, c->stream));
   int rc = 0;
   if (sb) {
-    void (*kern)(const FusedArgs) = want_gy ? (c->mixed ? pmf_fused_sb_kernel<true, true> : pmf_fused_sb_kernel<false, true>)
-                                            : (c->mixed ? pmf_fused_sb_kernel<true, false> : pmf_fused_sb_kernel<false, false>);
-    static bool sb_attr[4] = {false, false, false, false};
-    const int vi = (want_gy ? 2 : 0) + (c->mixed ? 1 : 0);
+    void (*kern)(const FusedArgs) = nullptr;
+    if (want_gx && want_gy) kern = c->mixed ? pmf_fused_sb_kernel<true, true, true> : pmf_fused_sb_kernel<false, true, true>;
+    else if (want_gx) kern = c->mixed ? pmf_fused_sb_kernel<true, true, false> : pmf_fused_sb_kernel<false, true, false>;
+    else kern = c->mixed ? pmf_fused_sb_kernel<true, false, true> : pmf_fused_sb_kernel<false, false, true>;
+    static bool sb_attr[8] = {};
+    const int vi = (want_gy ? 4 : 0) + (want_gx ? 2 : 0) + (c->mixed ? 1 : 0);
     if (!sb_attr[vi]) {
       HIPCHK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SbCfg::lds_bytes));
       sb_attr[vi] = true;

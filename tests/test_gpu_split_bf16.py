@@ -103,8 +103,8 @@ def test_split_bf16_agrees_with_exact_kernel_at_config_size(sctx):
 
 
 def test_split_bf16_falls_back_to_exact_kernel_outside_its_scope(sctx):
-    """K <= 32, K > 64, batch layers and grad(Y)-only launches have no split-bf16 variant yet: they must run the
-    exact kernel (and say so through the launch counter), not fail."""
+    """K <= 32, K > 64 and batch layers have no split-bf16 variant yet: they must run the exact kernel (and say so
+    through the launch counter), not fail."""
     ctx, n0 = sctx
     for case in (dict(M=301, N=143, K=32), dict(M=200, N=150, K=100),
                  dict(M=420, N=260, K=64, n_views=2, batch_views=2, n_batches=8, col_params=True)):
@@ -116,23 +116,23 @@ def test_split_bf16_falls_back_to_exact_kernel_outside_its_scope(sctx):
         m.m.n_yreg = 0
         _, gd = m.loss_and_grads(update_X=True, update_Y=True)
         assert rel_err(g["Y"], gd["Y"]) <= GRAD_TOL
-    p = make_problem(seed=11, **CASES["ragged_k64_nan"])
-    to_context(p, ctx)
-    grads_of(ctx, p, update_X=False, update_Y=True)
     assert ctx.get_precision()[1] == n0
 
 
+@pytest.mark.parametrize("which", ["X", "Y"])
 @pytest.mark.parametrize("name", ["ragged_k64_nan", "mixed_k48", "many_panels_k40"])
-def test_split_bf16_transform_mode_gradient_matches_oracle(sctx, name):
-    """grad(X)-only launches (transform: Y and the layers fixed, transform.jl) take the variant without GEMM3 / slabs."""
+def test_split_bf16_single_factor_gradient_matches_oracle(sctx, name, which):
+    """grad(X)-only launches (transform: Y and the layers fixed, transform.jl) take the variant without GEMM3 / slabs,
+    grad(Y)-only launches the one without GEMM2."""
     ctx, n0 = sctx
     p = make_problem(seed=13, **CASES[name])
     to_context(p, ctx)
-    loss, g = grads_of(ctx, p, update_X=True, update_Y=False)
+    flags = dict(update_X=which == "X", update_Y=which == "Y")
+    loss, g = grads_of(ctx, p, **flags)
     assert ctx.get_precision()[1] == n0 + 1
     m = to_oracle(p)
     m.m.n_xreg = 0
     m.m.n_yreg = 0
-    _, go = m.loss_and_grads(update_X=True, update_Y=False)
+    _, go = m.loss_and_grads(**flags)
     assert abs(loss - go["data_loss"]) <= LOSS_RTOL * abs(go["data_loss"]) + 1e-6
-    assert rel_err(g["X"], go["X"]) <= GRAD_TOL, rel_err(g["X"], go["X"])
+    assert rel_err(g[which], go[which]) <= GRAD_TOL, rel_err(g[which], go[which])
