@@ -1501,6 +1501,9 @@ static int launch_fused(pmf_ctx *c, bool want_gx, bool want_gy) {
   const int NW = c->KB <= 2 ? 8 : 4;
   int RBW = (c->KB == 1 && c->n_bv == 0) ? 2 : 1;
   if (rbwenv && c->KB == 1 && atoi(rbwenv) == 1) RBW = 1;
+  // split-bf16 products (opt-in, pmf_set_precision): K <= 64, no batch layers; one row block per wave
+  const bool sb = c->precision == PMF_PREC_BF16X3 && c->KB <= 2 && c->n_bv == 0 && (want_gx || want_gy) && !getenv("PMF_DEBUG_FLAGS");
+  if (sb) RBW = 1;
   const int BM = 32 * NW * RBW;
   const int64_t n_rp = (c->M + BM - 1) / BM;
   const int64_t n_ct = (c->N + PMF_BN - 1) / PMF_BN;  // column tiles
@@ -1563,16 +1566,20 @@ static int launch_fused(pmf_ctx *c, bool want_gx, bool want_gy) {
 #endif
   a.views = c->d_views;
   const bool batch = c->n_bv > 0;
-  // split-bf16 products (opt-in): first version covers 32 < K <= 64, no batch layers, both gradients
-  const bool sb = c->precision == PMF_PREC_BF16X3 && c->KB == 2 && !batch && (want_gx || want_gy) && a.dbg == 0;
   if (sb) {
-    const size_t xb = (size_t)c->nRB * PMF_SB_BLK, yb = (size_t)n_ct * PMF_SB_BLK;
+    const size_t blk = c->KB == 1 ? SbCfg<1>::BLK : SbCfg<2>::BLK;
+    const size_t xb = (size_t)c->nRB * blk, yb = (size_t)n_ct * blk;
     if (xb > c->xsb_cap) { dev_free(&c->xsb); c->xsb_cap = 0; PMFCHK(dev_alloc(&c->xsb, xb, false)); c->xsb_cap = xb; }
     if (yb > c->ysb_cap) { dev_free(&c->ysb); c->ysb_cap = 0; PMFCHK(dev_alloc(&c->ysb, yb, false)); c->ysb_cap = yb; }
     SbSplitArgs sx = {c->P[0].p, nullptr, c->M, c->nRB, c->xsb};
     SbSplitArgs sy = {c->P[1].p, c->colp, c->N, n_ct, c->ysb};
-    k_sb_split<<<nblocks(c->nRB * 32 * 8, 256), 256, 0, c->stream>>>(sx);
-    k_sb_split<<<nblocks(n_ct * 32 * 8, 256), 256, 0, c->stream>>>(sy);
+    if (c->KB == 1) {
+      k_sb_split<1><<<nblocks(c->nRB * 32 * 4, 256), 256, 0, c->stream>>>(sx);
+      k_sb_split<1><<<nblocks(n_ct * 32 * 4, 256), 256, 0, c->stream>>>(sy);
+    } else {
+      k_sb_split<2><<<nblocks(c->nRB * 32 * 8, 256), 256, 0, c->stream>>>(sx);
+      k_sb_split<2><<<nblocks(n_ct * 32 * 8, 256), 256, 0, c->stream>>>(sy);
+    }
     HIPCHK(hipGetLastError());
     a.Xsb = c->xsb; a.Ysb = c->ysb;
   }
@@ -1593,16 +1600,19 @@ static int launch_fused(pmf_ctx *c, bool want_gx, bool want_gy) {
   int rc = 0;
   if (sb) {
     void (*kern)(const FusedArgs) = nullptr;
-    if (want_gx && want_gy) kern = c->mixed ? pmf_fused_sb_kernel<true, true, true> : pmf_fused_sb_kernel<false, true, true>;
-    else if (want_gx) kern = c->mixed ? pmf_fused_sb_kernel<true, true, false> : pmf_fused_sb_kernel<false, true, false>;
-    else kern = c->mixed ? pmf_fused_sb_kernel<true, false, true> : pmf_fused_sb_kernel<false, false, true>;
-    static bool sb_attr[8] = {};
-    const int vi = (want_gy ? 4 : 0) + (want_gx ? 2 : 0) + (c->mixed ? 1 : 0);
+#define PMF_SB_PICK(KBv) (want_gx && want_gy ? (c->mixed ? pmf_fused_sb_kernel<KBv, true, true, true> : pmf_fused_sb_kernel<KBv, false, true, true>) \
+                          : want_gx ? (c->mixed ? pmf_fused_sb_kernel<KBv, true, true, false> : pmf_fused_sb_kernel<KBv, false, true, false>)          \
+                                    : (c->mixed ? pmf_fused_sb_kernel<KBv, true, false, true> : pmf_fused_sb_kernel<KBv, false, false, true>))
+    kern = c->KB == 1 ? PMF_SB_PICK(1) : PMF_SB_PICK(2);
+#undef PMF_SB_PICK
+    const size_t lds = c->KB == 1 ? SbCfg<1>::lds_bytes : SbCfg<2>::lds_bytes;
+    static bool sb_attr[16] = {};
+    const int vi = (c->KB == 1 ? 8 : 0) + (want_gy ? 4 : 0) + (want_gx ? 2 : 0) + (c->mixed ? 1 : 0);
     if (!sb_attr[vi]) {
-      HIPCHK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SbCfg::lds_bytes));
+      HIPCHK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       sb_attr[vi] = true;
     }
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), SbCfg::lds_bytes, c->stream, a);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, c->stream, a);
     HIPCHK(hipGetLastError());
     c->sb_launches += 1;
   } else

@@ -1,5 +1,7 @@
 """Randomised parity sweep: HIP path vs the fp64 oracle on random shapes / models (development aid, GPU box).
-python scripts/fuzz_parity.py [n_cases] [seed]"""
+python scripts/fuzz_parity.py [n_cases] [seed] [split]
+"split" draws the cases from the scope of the opt-in split-bf16 kernel (K <= 64, no batch layers; both gradients,
+grad(X) only or grad(Y) only), selects it with pmf_set_precision and checks that it was the kernel launched."""
 import sys
 from pathlib import Path
 import numpy as np
@@ -12,15 +14,22 @@ from problems import make_problem, rel_err, to_context, to_oracle
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 60
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 ctx = pkg.Context(0)
+SPLIT = len(sys.argv) > 3 and sys.argv[3] == "split"
+if SPLIT:
+    ctx.set_precision("bf16x3")
 worst = dict(loss=0.0, gx=0.0, gy=0.0, layer=0.0)
 for c in range(n_cases):
     K = int(rng.choice([1, 2, 4, 7, 16, 31, 32, 33, 64, 65, 96, 100, 128]))
     M = int(rng.choice([1, 3, 31, 32, 33, 255, 256, 257, 600, 1500, 5000, 20000, 70000]))
     N = int(rng.choice([1, 5, 31, 32, 33, 63, 64, 65, 200, 777, 2500]))
+    if SPLIT:
+        K = int(rng.integers(1, 65))
     if M * N * max(K, 8) > 6e8:   # keep the fp64 oracle in seconds
         N = int(rng.choice([33, 64, 100, 257]))
     nv = int(rng.integers(1, 4))
     bv = int(rng.integers(0, nv + 1)) if N >= 3 * nv else 0
+    if SPLIT:
+        bv = 0
     nb = int(rng.choice([1, 2, 4, 9, 15, 16, 23]))
     bern = float(rng.choice([0.0, 0.0, 0.3, 1.0]))
     pois = float(rng.choice([0.0, 0.0, 0.2])) if bern < 1.0 else 0.0
@@ -34,15 +43,20 @@ for c in range(n_cases):
         print(f"case {c}: generator skipped {kw}: {e}")
         continue
     to_context(p, ctx)
-    o = ctx.make_opts(update_X=True, update_Y=True)
+    mode = int(rng.integers(0, 3)) if SPLIT else 0          # 0 both gradients, 1 grad(X) only, 2 grad(Y) only
+    ux, uy = mode != 2, mode != 1
+    o = ctx.make_opts(update_X=ux, update_Y=uy)
+    n_split0 = ctx.get_precision()[1]
     ctx.epoch_begin(o)
     loss, _ = ctx.epoch_loss()
-    gx, gy = ctx.get_grad("X"), ctx.get_grad("Y")
+    if SPLIT and ctx.get_precision()[1] != n_split0 + 1:
+        print(f"case {c}: FAIL the split-bf16 kernel was not launched for {kw}")
+    gx, gy = (ctx.get_grad("X") if ux else None), (ctx.get_grad("Y") if uy else None)
     m = to_oracle(p)
     m.m.n_xreg = 0; m.m.n_yreg = 0
-    lo, go = m.loss_and_grads(update_X=True, update_Y=True)
+    lo, go = m.loss_and_grads(update_X=ux, update_Y=uy)
     el = abs(loss - go["data_loss"]) / (abs(go["data_loss"]) + 1e-6)
-    ex, ey = rel_err(gx, go["X"]), rel_err(gy, go["Y"])
+    ex, ey = (rel_err(gx, go["X"]) if ux else 0.0), (rel_err(gy, go["Y"]) if uy else 0.0)
     el2 = 0.0
     if p["batch_views"] or kw["col_params"]:
         o2 = ctx.make_opts(update_col_layers=True)
@@ -56,6 +70,6 @@ for c in range(n_cases):
             el2 = max(el2, rel_err(ctx.get_grad("theta", v), g2["theta"][v]), rel_err(ctx.get_grad("logdelta", v), g2["logdelta"][v]))
     bad = el > 2e-5 or ex > 2e-4 or ey > 2e-4 or el2 > 2e-4 or not np.isfinite([el, ex, ey, el2]).all()
     worst = dict(loss=max(worst["loss"], el), gx=max(worst["gx"], ex), gy=max(worst["gy"], ey), layer=max(worst["layer"], el2))
-    print(f"case {c:3d} {'FAIL' if bad else 'ok  '} M={M} N={N} K={K} views={nv}/{bv} nb={nb} bern={bern} pois={pois} nan={kw['nan_frac']}: "
+    print(f"case {c:3d} {'FAIL' if bad else 'ok  '} mode={mode} M={M} N={N} K={K} views={nv}/{bv} nb={nb} bern={bern} pois={pois} nan={kw['nan_frac']}: "
           f"loss {el:.1e} gX {ex:.1e} gY {ey:.1e} layers {el2:.1e}", flush=True)
 print("worst:", worst)

@@ -26,6 +26,13 @@ CASES = {
     # two-tile segments and more work items than workgroups: consecutive pieces of a workgroup re-read private-slab
     # entries they stored a moment ago (the prefetch runs a tile ahead of the store)
     "many_panels_two_tiles": dict(M=70000, N=40, K=64, weights=True, scale=0.5),
+    # K <= 32: the one-k-block variant (64-byte image rows, its own swizzle; the gY tile has half as many float4 as threads)
+    "ragged_k32": dict(M=301, N=143, K=32, yreg="fsard", xreg="group", weights=True, col_params=True),
+    "k10_pad": dict(M=260, N=70, K=10, yreg="ard", n_views=2, col_params=True),
+    "tiny_k2": dict(M=5, N=7, K=2),
+    "mixed_k17": dict(M=600, N=420, K=17, bernoulli_frac=0.25, poisson_frac=0.15, n_views=3, nan_frac=0.08, weights=True,
+                      col_params=True, scale=0.4),
+    "many_panels_k8": dict(M=70000, N=600, K=8, xreg="l2", weights=True, col_params=True),
 }
 
 
@@ -54,9 +61,10 @@ def test_split_bf16_loss_and_gradients_match_oracle(sctx, name):
 
 
 @pytest.mark.parametrize("opt", ["adagrad", "adam"])
-def test_split_bf16_fit_trajectory_matches_oracle(sctx, opt):
+@pytest.mark.parametrize("name", ["ragged_k64_nan", "ragged_k32"])
+def test_split_bf16_fit_trajectory_matches_oracle(sctx, opt, name):
     ctx, n0 = sctx
-    p = make_problem(seed=13, random_init=True, **CASES["ragged_k64_nan"])
+    p = make_problem(seed=13, random_init=True, **CASES[name])
     lr = 0.05 if opt == "adagrad" else 0.01
     to_context(p, ctx)
     ctx.set_optimizer(opt, lr=lr)
@@ -103,10 +111,10 @@ def test_split_bf16_agrees_with_exact_kernel_at_config_size(sctx):
 
 
 def test_split_bf16_falls_back_to_exact_kernel_outside_its_scope(sctx):
-    """K <= 32, K > 64 and batch layers have no split-bf16 variant yet: they must run the exact kernel (and say so
-    through the launch counter), not fail."""
+    """K > 64 and batch layers have no split-bf16 variant yet: they must run the exact kernel (and say so through the
+    launch counter), not fail."""
     ctx, n0 = sctx
-    for case in (dict(M=301, N=143, K=32), dict(M=200, N=150, K=100),
+    for case in (dict(M=200, N=150, K=100),
                  dict(M=420, N=260, K=64, n_views=2, batch_views=2, n_batches=8, col_params=True)):
         p = make_problem(seed=11, **case)
         to_context(p, ctx)
@@ -120,7 +128,7 @@ def test_split_bf16_falls_back_to_exact_kernel_outside_its_scope(sctx):
 
 
 @pytest.mark.parametrize("which", ["X", "Y"])
-@pytest.mark.parametrize("name", ["ragged_k64_nan", "mixed_k48", "many_panels_k40"])
+@pytest.mark.parametrize("name", ["ragged_k64_nan", "mixed_k48", "many_panels_k40", "ragged_k32", "many_panels_k8"])
 def test_split_bf16_single_factor_gradient_matches_oracle(sctx, name, which):
     """grad(X)-only launches (transform: Y and the layers fixed, transform.jl) take the variant without GEMM3 / slabs,
     grad(Y)-only launches the one without GEMM2."""
