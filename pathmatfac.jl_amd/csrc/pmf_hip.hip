@@ -1502,7 +1502,9 @@ static int launch_fused(pmf_ctx *c, bool want_gx, bool want_gy) {
   int RBW = (c->KB == 1 && c->n_bv == 0) ? 2 : 1;
   if (rbwenv && c->KB == 1 && atoi(rbwenv) == 1) RBW = 1;
   // split-bf16 products (opt-in, pmf_set_precision): K <= 64, no batch layers; one row block per wave
-  const bool sb = c->precision == PMF_PREC_BF16X3 && c->KB <= 2 && c->n_bv == 0 && (want_gx || want_gy) && !getenv("PMF_DEBUG_FLAGS");
+  // (batch layers: through the dense LDS table only, i.e. <= 15 batches per view, and as many views as LDS has room for)
+  const bool sb_batch_ok = c->n_bv == 0 || (c->btd_ok && c->n_bv <= (c->KB == 1 ? SbCfg<1>::max_bv : SbCfg<2>::max_bv));
+  const bool sb = c->precision == PMF_PREC_BF16X3 && c->KB <= 2 && sb_batch_ok && (want_gx || want_gy) && !getenv("PMF_DEBUG_FLAGS");
   if (sb) RBW = 1;
   const int BM = 32 * NW * RBW;
   const int64_t n_rp = (c->M + BM - 1) / BM;
@@ -1600,17 +1602,19 @@ static int launch_fused(pmf_ctx *c, bool want_gx, bool want_gy) {
   int rc = 0;
   if (sb) {
     void (*kern)(const FusedArgs) = nullptr;
-#define PMF_SB_PICK(KBv) (want_gx && want_gy ? (c->mixed ? pmf_fused_sb_kernel<KBv, true, true, true> : pmf_fused_sb_kernel<KBv, false, true, true>) \
-                          : want_gx ? (c->mixed ? pmf_fused_sb_kernel<KBv, true, true, false> : pmf_fused_sb_kernel<KBv, false, true, false>)          \
-                                    : (c->mixed ? pmf_fused_sb_kernel<KBv, true, false, true> : pmf_fused_sb_kernel<KBv, false, false, true>))
+    // (the batch-layer variants exist with the per-tile noise-model dispatch only: MIXED = true also serves uniform models)
+#define PMF_SB_PICK_G(KBv, MX, BT) (want_gx && want_gy ? pmf_fused_sb_kernel<KBv, MX, true, true, BT>                                        \
+                                    : want_gx ? pmf_fused_sb_kernel<KBv, MX, true, false, BT> : pmf_fused_sb_kernel<KBv, MX, false, true, BT>)
+#define PMF_SB_PICK(KBv) (batch ? PMF_SB_PICK_G(KBv, true, true) : (c->mixed ? PMF_SB_PICK_G(KBv, true, false) : PMF_SB_PICK_G(KBv, false, false)))
     kern = c->KB == 1 ? PMF_SB_PICK(1) : PMF_SB_PICK(2);
 #undef PMF_SB_PICK
-    const size_t lds = c->KB == 1 ? SbCfg<1>::lds_bytes : SbCfg<2>::lds_bytes;
-    static bool sb_attr[16] = {};
-    const int vi = (c->KB == 1 ? 8 : 0) + (want_gy ? 4 : 0) + (want_gx ? 2 : 0) + (c->mixed ? 1 : 0);
-    if (!sb_attr[vi]) {
+#undef PMF_SB_PICK_G
+    const size_t lds = (c->KB == 1 ? SbCfg<1>::lds_bytes : SbCfg<2>::lds_bytes) + (batch ? SbCfg<1>::lds_batch(c->n_bv) : 0);
+    static size_t sb_attr[32] = {};   // largest dynamic LDS size set so far, per variant
+    const int vi = (batch ? 16 : 0) + (c->KB == 1 ? 8 : 0) + (want_gy ? 4 : 0) + (want_gx ? 2 : 0) + (c->mixed ? 1 : 0);
+    if (sb_attr[vi] < lds) {
       HIPCHK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      sb_attr[vi] = true;
+      sb_attr[vi] = lds;
     }
     hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, c->stream, a);
     HIPCHK(hipGetLastError());

@@ -33,6 +33,15 @@ CASES = {
     "mixed_k17": dict(M=600, N=420, K=17, bernoulli_frac=0.25, poisson_frac=0.15, n_views=3, nan_frac=0.08, weights=True,
                       col_params=True, scale=0.4),
     "many_panels_k8": dict(M=70000, N=600, K=8, xreg="l2", weights=True, col_params=True),
+    # batch scale / shift layers (BASELINE config 3 flavour) through the LDS-staged dense batch table
+    "mixed_batch_nan_k32": dict(M=420, N=260, K=32, bernoulli_frac=0.2, n_views=2, batch_views=2, n_batches=8,
+                                nan_frac=0.1, weights=True, col_params=True, xreg="composite", yreg="fsard"),
+    "mixed_batch_nan_k64": dict(M=420, N=260, K=64, bernoulli_frac=0.2, n_views=2, batch_views=2, n_batches=8,
+                                nan_frac=0.1, weights=True, col_params=True, scale=0.5),
+    "poisson_batch_k8": dict(M=150, N=90, K=8, poisson_frac=0.3, bernoulli_frac=0.2, n_views=3, batch_views=2,
+                             weights=True, col_params=True, scale=0.4),
+    "batch_many_panels_k40": dict(M=30000, N=300, K=40, n_views=3, batch_views=3, n_batches=15, nan_frac=0.05, scale=0.5,
+                                  col_params=True),
 }
 
 
@@ -111,11 +120,11 @@ def test_split_bf16_agrees_with_exact_kernel_at_config_size(sctx):
 
 
 def test_split_bf16_falls_back_to_exact_kernel_outside_its_scope(sctx):
-    """K > 64 and batch layers have no split-bf16 variant yet: they must run the exact kernel (and say so through the
-    launch counter), not fail."""
+    """K > 64 and views with more than 15 batches (no dense LDS batch table) have no split-bf16 variant: they must run the
+    exact kernel (and say so through the launch counter), not fail."""
     ctx, n0 = sctx
     for case in (dict(M=200, N=150, K=100),
-                 dict(M=420, N=260, K=64, n_views=2, batch_views=2, n_batches=8, col_params=True)):
+                 dict(M=300, N=100, K=16, n_views=2, batch_views=2, n_batches=20, nan_frac=0.05, col_params=True)):
         p = make_problem(seed=11, **case)
         to_context(p, ctx)
         loss, g = grads_of(ctx, p, update_X=True, update_Y=True)
@@ -128,7 +137,8 @@ def test_split_bf16_falls_back_to_exact_kernel_outside_its_scope(sctx):
 
 
 @pytest.mark.parametrize("which", ["X", "Y"])
-@pytest.mark.parametrize("name", ["ragged_k64_nan", "mixed_k48", "many_panels_k40", "ragged_k32", "many_panels_k8"])
+@pytest.mark.parametrize("name", ["ragged_k64_nan", "mixed_k48", "many_panels_k40", "ragged_k32", "many_panels_k8",
+                                  "mixed_batch_nan_k32", "mixed_batch_nan_k64"])
 def test_split_bf16_single_factor_gradient_matches_oracle(sctx, name, which):
     """grad(X)-only launches (transform: Y and the layers fixed, transform.jl) take the variant without GEMM3 / slabs,
     grad(Y)-only launches the one without GEMM2."""
