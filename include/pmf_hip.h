@@ -212,7 +212,7 @@ int pmf_stats(pmf_ctx *ctx, int use_factors, float *col_n, float *col_sum, float
  *   PMF_PREC_F32    (default) exact f32 MFMA, v_mfma_f32_32x32x2_f32
  *   PMF_PREC_BF16X3 split-bf16: every f32 operand as a bf16 hi/lo pair, three bf16 MFMAs per product, f32 accumulation;
  *                   a six-term forward product as accurate as the f32 MFMA (2e-7 of max|Z|), three-term gradient products
- *                   (4e-6).  Used where a kernel variant exists (K <= 64, no batch layers); every other launch silently
+ *                   (4e-6).  Used where a kernel variant exists (K <= 64, at most 15 batches per view); every other launch silently
  *                   stays exact.
  * pmf_get_precision also reports how many fused launches of this context took the split-bf16 kernel. */
 #define PMF_PREC_F32 0
