@@ -15,6 +15,9 @@ ctx.set_data_device(None, M, N)
 ctx.set_factors((rng.standard_normal((K, M)) * 0.3).astype(np.float32), (rng.standard_normal((K, N)) * 0.3).astype(np.float32))
 ctx.set_col_params(np.zeros(N, np.float32), np.zeros(N, np.float32)); ctx.set_batch_views([])
 ctx.set_noise([(1, N)], ["normal"], np.ones(N, np.float32)); ctx.synth_data(seed=5, noise=0.1)
+import os
+if os.environ.get("PMF_ZERO") == "1":   # all-zero operands and data: what the clock does when the datapaths do not toggle
+    ctx.set_factors(np.zeros((K, M), np.float32), np.zeros((K, N), np.float32)); ctx.synth_data(seed=5, noise=0.0)
 o = ctx.make_opts(update_X=True, update_Y=True)
 for _ in range(int(sys.argv[4]) if len(sys.argv) > 4 else 3): ctx.epoch_begin(o)   # >= 2 s of launches before reading the clock
 ctx.epoch_loss(); ctx.kernel_time(reset=True)
