@@ -66,6 +66,12 @@ def main():
                          "split-bf16 kernel; the other mode is timed afterwards on the same data and reported beside it")
     args = ap.parse_args()
 
+    # stdout carries exactly ONE line, the JSON: everything libraries print there meanwhile (RCCL's version banner at the
+    # first collective, for one) goes to stderr
+    sys.stdout.flush()
+    stdout_fd = os.dup(1)
+    os.dup2(2, 1)
+
     import torch
     import pmf_import
     pkg = pmf_import.load()
@@ -224,7 +230,10 @@ def main():
                                    "kind": "port",
                                    "sample": f"CPU oracle (float build, OpenMP) on {rows} of {M} rows x {N} cols, K={K}, "
                                              f"{ep} epochs timed ({t_epoch:.2f} s/epoch on the sample), scaled by {M}/{rows}"}
+        sys.stdout.flush()
+        os.dup2(stdout_fd, 1)
         print(json.dumps(out), flush=True)
+        os.dup2(2, 1)
     ctx.close()
     if use_dist:
         dist.destroy_process_group()
