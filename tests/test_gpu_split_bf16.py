@@ -11,6 +11,7 @@ import numpy as np
 import pytest
 
 from problems import make_problem, rel_err, to_context, to_oracle
+import test_gpu_parity as exact_tests
 from test_gpu_parity import FIT_TOL, GRAD_TOL, LOSS_RTOL, grads_of
 
 pytestmark = pytest.mark.gpu
@@ -154,3 +155,12 @@ def test_split_bf16_single_factor_gradient_matches_oracle(sctx, name, which):
     _, go = m.loss_and_grads(**flags)
     assert abs(loss - go["data_loss"]) <= LOSS_RTOL * abs(go["data_loss"]) + 1e-6
     assert rel_err(g[which], go[which]) <= GRAD_TOL, rel_err(g[which], go[which])
+
+
+def test_split_bf16_headline_size_properties(sctx):
+    """The size-independent properties of tests/test_gpu_parity.py at BASELINE.json's headline configuration
+    (200000 x 50000, K = 64: loss against the independent statistics kernel, gradient consistent with the loss by a
+    Richardson-extrapolated directional derivative, bitwise reproducibility), through the split-bf16 kernel."""
+    ctx, n0 = sctx
+    exact_tests.test_headline_size_loss_and_gradient_consistency(ctx)
+    assert ctx.get_precision()[1] == n0 + 4, "the split-bf16 kernel was not launched"
