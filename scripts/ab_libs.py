@@ -20,7 +20,7 @@ for lp in libs:
     ctx.set_factors(X0, Y0)
     ctx.set_optimizer("adagrad", lr=0.05)
     ctxs.append(ctx)
-for rnd in range(3):
+for rnd in range(int(__import__("os").environ.get("PMF_AB_ROUNDS", "3"))):
     for lp, ctx in zip(libs, ctxs):
         ctx.fit(update_X=True, update_Y=True, max_epochs=1, abs_tol=0, rel_tol=0)
         ctx.kernel_time(reset=True)
