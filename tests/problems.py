@@ -171,3 +171,24 @@ def rel_err(a, b):
     b = np.asarray(b, dtype=np.float64)
     denom = max(np.max(np.abs(b)), 1e-30)
     return float(np.max(np.abs(a - b)) / denom)
+
+
+def shard_problem(p, lo, hi):
+    """Rows [lo, hi) of the problem as a problem of its own (what one rank of the row-sharded fit holds): D, X and the
+    row -> batch maps are sliced, X-regularizer groups (ranges over the GLOBAL rows) are clipped to the shard, everything
+    indexed by columns is replicated."""
+    import copy
+    q = copy.deepcopy(p)
+    q["D"] = np.asfortranarray(p["D"][lo:hi])
+    q["X"] = np.asfortranarray(p["X"][:, lo:hi])
+    q["M"] = hi - lo
+    for b in q["batch_views"]:
+        b["batch_of_row"] = np.ascontiguousarray(b["batch_of_row"][lo:hi])
+    for t in q["xreg"]:
+        if t["kind"] == "group":
+            s = [max(a, lo + 1) - lo for a in t["start1"]]
+            e = [min(b, hi) - lo for b in t["stop1"]]
+            keep = [i for i in range(len(s)) if e[i] >= s[i]]
+            t["start1"], t["stop1"] = [s[i] for i in keep], [e[i] for i in keep]
+            t["w"] = np.asarray(t["w"])[keep]
+    return q
