@@ -98,7 +98,10 @@ int pmf_version(void);
 /* gpu(model) / cpu(model): analyses/scripts/julia/fit_matfac.jl:325-340, src/transform.jl:78-94 */
 int pmf_create(int device, pmf_ctx **out);
 int pmf_destroy(pmf_ctx *ctx);
-/* adopt an existing hipStream_t (e.g. the host framework's current stream); NULL = library-owned stream */
+/* adopt an existing hipStream_t (e.g. the host framework's current stream); NULL = library-owned (non-blocking) stream.
+ * The legacy DEFAULT stream is not NULL here: pass hipStreamLegacy ((hipStream_t)1).  A host whose collectives are
+ * ordered behind the default stream (torch reports it as handle 0) must do so, or the library's kernels on its own
+ * stream are not ordered with them. */
 int pmf_set_stream(pmf_ctx *ctx, void *hip_stream);
 int pmf_synchronize(pmf_ctx *ctx);
 

@@ -131,7 +131,16 @@ class Context:
 
     # ---- data / parameters
     def set_stream(self, stream_ptr):
-        self._chk(self.lib.pmf_set_stream(self._h, C.c_void_p(stream_ptr)))
+        """Runs the library's kernels on the caller's HIP stream, e.g. torch.cuda.current_stream().cuda_stream, so that
+        they order with the caller's collectives.  torch reports its DEFAULT stream as handle 0, which pmf_set_stream
+        reads as "back to the library's own (non-blocking) stream" -- kernels there would NOT be ordered with work torch
+        or RCCL issue behind the default stream -- so 0 is passed on as hipStreamLegacy, the legacy default stream itself."""
+        HIP_STREAM_LEGACY = 1   # hip_runtime_api.h: #define hipStreamLegacy ((hipStream_t)1)
+        self._chk(self.lib.pmf_set_stream(self._h, C.c_void_p(stream_ptr if stream_ptr else HIP_STREAM_LEGACY)))
+
+    def use_own_stream(self):
+        """Back to the library's own non-blocking stream (pmf_set_stream(ctx, NULL))."""
+        self._chk(self.lib.pmf_set_stream(self._h, C.c_void_p(0)))
 
     def synchronize(self):
         self._chk(self.lib.pmf_synchronize(self._h))

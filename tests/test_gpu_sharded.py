@@ -20,10 +20,22 @@ ROOT = Path(__file__).resolve().parent.parent
 
 CASE = dict(M=1500, N=420, K=48, seed=31, bernoulli_frac=0.2, nan_frac=0.05, weights=True, col_params=True, n_views=2,
             batch_views=2, n_batches=6, xreg="group", yreg="fsard", random_init=True, n_groups=5, scale=0.5)
-EPOCHS, LR = 8, 0.05
+EPOCHS, LR = int(os.environ.get("PMF_SHARD_EPOCHS", "8")), 0.05
 
 
-def _worker(rank, world, port, outdir, precision):
+def _flags(mode):
+    return dict(update_X=True, update_Y=True) if mode == "factors" else dict(update_col_layers=True)
+
+
+def _layer_params(ctx, n_views):
+    ls, mu = ctx.get_col_params()
+    out = [ls, mu]
+    for v in range(n_views):
+        out += list(ctx.get_batch_view(v))
+    return np.concatenate([np.asarray(a, np.float64).ravel() for a in out])
+
+
+def _worker(rank, world, port, outdir, precision, mode="factors"):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     import torch
     import torch.distributed as dist
@@ -38,10 +50,10 @@ def _worker(rank, world, port, outdir, precision):
     ctx.set_precision(precision)
     to_context(shard_problem(p, lo, hi), ctx)
     ctx.set_optimizer("adagrad", lr=LR)
-    h = pkg.parallel.fit_distributed(ctx, dist=dist, update_X=True, update_Y=True, max_epochs=EPOCHS, abs_tol=0, rel_tol=0)
+    h = pkg.parallel.fit_distributed(ctx, dist=dist, max_epochs=EPOCHS, abs_tol=0, rel_tol=0, **_flags(mode))
     X, Y = ctx.get_factors()
     np.savez(Path(outdir) / f"rank{rank}.npz", X=X, Y=Y, loss=h["loss"], lo=lo, hi=hi, term=h["term_code"],
-             epochs=h["epochs"], split_launches=ctx.get_precision()[1])
+             epochs=h["epochs"], split_launches=ctx.get_precision()[1], layers=_layer_params(ctx, len(p["batch_views"])))
     ctx.close()
     dist.destroy_process_group()
 
@@ -52,7 +64,7 @@ def test_two_rank_sharded_hip_fit_matches_single_context_and_oracle(ctx, tmp_pat
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     code = ("import sys; sys.path[:0] = [%r, %r]; import test_gpu_sharded as t; "
-            "t._worker(int(sys.argv[1]), 2, int(sys.argv[2]), sys.argv[3], sys.argv[4])") % (str(ROOT), str(ROOT / "tests"))
+            "t._worker(int(sys.argv[1]), 2, int(sys.argv[2]), sys.argv[3], sys.argv[4], *sys.argv[5:])") % (str(ROOT), str(ROOT / "tests"))
     procs = [subprocess.Popen([sys.executable, "-c", code, str(r), str(port), str(tmp_path), precision]) for r in range(2)]
     for pr in procs:
         assert pr.wait(timeout=600) == 0
@@ -80,3 +92,28 @@ def test_two_rank_sharded_hip_fit_matches_single_context_and_oracle(ctx, tmp_pat
     np.testing.assert_array_equal(outs[0]["Y"], outs[1]["Y"])      # the replicated Y stays bit-identical across ranks
     assert rel_err(outs[0]["Y"], Y1) <= 2e-4 and rel_err(X, X1) <= 2e-4, (rel_err(outs[0]["Y"], Y1), rel_err(X, X1))
     assert rel_err(outs[0]["Y"], m.Y) <= 2e-3 and rel_err(X, m.X) <= 2e-3
+
+
+def test_two_rank_sharded_layer_stage_matches_single_context(ctx, tmp_path):
+    """The column / batch layer stage (update_col_layers: mu, theta, logdelta trained, X and Y fixed): the layer
+    gradients of the two row shards are summed through the all-reduce (a row batch spans both ranks), and every rank
+    must end with the single-context parameters."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    code = ("import sys; sys.path[:0] = [%r, %r]; import test_gpu_sharded as t; "
+            "t._worker(int(sys.argv[1]), 2, int(sys.argv[2]), sys.argv[3], sys.argv[4], *sys.argv[5:])") % (str(ROOT), str(ROOT / "tests"))
+    procs = [subprocess.Popen([sys.executable, "-c", code, str(r), str(port), str(tmp_path), "f32", "layers"]) for r in range(2)]
+    for pr in procs:
+        assert pr.wait(timeout=600) == 0
+    outs = [np.load(tmp_path / f"rank{k}.npz") for k in range(2)]
+    p = make_problem(**CASE)
+    to_context(p, ctx)
+    ctx.set_optimizer("adagrad", lr=LR)
+    r1 = ctx.fit(update_col_layers=True, max_epochs=EPOCHS, abs_tol=0, rel_tol=0)
+    ref = _layer_params(ctx, len(p["batch_views"]))
+    for o in outs:
+        assert str(o["term"]) == r1["term_code"] and int(o["epochs"]) == r1["epochs"]
+        np.testing.assert_allclose(o["loss"], r1["loss"], rtol=2e-5)
+        assert rel_err(o["layers"], ref) <= 2e-4, rel_err(o["layers"], ref)
+    np.testing.assert_array_equal(outs[0]["layers"], outs[1]["layers"])
