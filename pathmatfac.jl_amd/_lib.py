@@ -137,10 +137,12 @@ class Context:
         or RCCL issue behind the default stream -- so 0 is passed on as hipStreamLegacy, the legacy default stream itself."""
         HIP_STREAM_LEGACY = 1   # hip_runtime_api.h: #define hipStreamLegacy ((hipStream_t)1)
         self._chk(self.lib.pmf_set_stream(self._h, C.c_void_p(stream_ptr if stream_ptr else HIP_STREAM_LEGACY)))
+        self._stream_adopted = True
 
     def use_own_stream(self):
         """Back to the library's own non-blocking stream (pmf_set_stream(ctx, NULL))."""
         self._chk(self.lib.pmf_set_stream(self._h, C.c_void_p(0)))
+        self._stream_adopted = False
 
     def synchronize(self):
         self._chk(self.lib.pmf_synchronize(self._h))

@@ -56,6 +56,9 @@ def fit_distributed(ctx, dist=None, group=None, update_X=False, update_Y=False, 
                       frozen_layers=frozen_layers, frozen_regs=frozen_regs, max_epochs=max_epochs, epoch=epoch,
                       abs_tol=abs_tol, rel_tol=rel_tol, tol_max_iters=tol_max_iters)
     shared = []
+    if world > 1 and hasattr(ctx, "set_stream") and not getattr(ctx, "_stream_adopted", False):
+        # the collectives below are ordered behind torch's current stream: the library's kernels must run there too
+        ctx.set_stream(torch.cuda.current_stream().cuda_stream)
     if world > 1:
         if update_Y:
             shared.append(grad_tensor(ctx, "Y"))

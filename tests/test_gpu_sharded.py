@@ -46,7 +46,7 @@ def _worker(rank, world, port, outdir, precision, mode="factors"):
     p = make_problem(**CASE)
     lo, hi = pkg.parallel.shard_rows(p["M"], world, rank)
     ctx = pkg.Context(0)
-    ctx.set_stream(torch.cuda.current_stream().cuda_stream)   # the library's kernels and the collectives order through one stream
+    # (no set_stream here on purpose: fit_distributed must adopt torch's current stream itself when world_size > 1)
     ctx.set_precision(precision)
     to_context(shard_problem(p, lo, hi), ctx)
     ctx.set_optimizer("adagrad", lr=LR)
