@@ -66,36 +66,70 @@ def main():
                          "split-bf16 kernel; the other mode is timed afterwards on the same data and reported beside it")
     args = ap.parse_args()
 
+    world = int(os.environ.get("WORLD_SIZE", "0") or 0)
+    if world == 0 and args.gpus > 1:
+        # Started directly with --gpus N: start the N ranks ourselves (one process per GPU), BEFORE anything touches the
+        # GPU or imports torch in this process, relay rank 0's JSON line and exit with the launcher's code.
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), str(Path(__file__).resolve())] + sys.argv[1:]
+        sys.exit(subprocess.run(cmd).returncode)
+    world = max(world, 1)
+    if args.gpus != world:
+        print(f"error: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
+        sys.exit(2)
+
     # stdout carries exactly ONE line, the JSON: everything libraries print there meanwhile (RCCL's version banner at the
     # first collective, for one) goes to stderr
     sys.stdout.flush()
     stdout_fd = os.dup(1)
     os.dup2(2, 1)
 
-    import torch
+    # The rank processes never import torch: the GPU is driven through libpmf_hip.so alone (ONE HIP runtime, the system
+    # ROCm's, and the RCCL that belongs to it); "torch.cuda.synchronize()" of the contract is ctx.synchronize() here, and
+    # the barrier / max over ranks go through the library's communicator (pmf_comm_allreduce).
+    os.environ["PMF_NO_TORCH"] = "1"
     import pmf_import
     pkg = pmf_import.load()
     from pathmatfac_jl_amd import parallel
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    dist = None
-    force_dist = os.environ.get("PMF_FORCE_DIST", "0") == "1"   # exercise the RCCL path with a 1-rank group (testing)
-    if world > 1 or force_dist:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
-    if args.gpus != world and rank == 0:
-        print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using {world}", file=sys.stderr)
-    torch.cuda.set_device(local_rank)
+    force_dist = os.environ.get("PMF_FORCE_DIST", "0") == "1"   # exercise the RCCL path with a 1-rank communicator (testing)
+    use_dist = world > 1 or force_dist
     M, N, K = args.M, args.N, args.K
     lo, hi = parallel.shard_rows(M, world, rank)
     Ml = hi - lo
 
     ctx = pkg.Context(local_rank)
-    ctx.set_stream(torch.cuda.current_stream().cuda_stream)   # kernels and RCCL order through torch's stream
+    uid_file = None
+    if use_dist:
+        # ncclUniqueId: created by rank 0, handed to the others through a file (one node; the ranks share their parent,
+        # the launcher).  Everything after that goes over RCCL.
+        key = os.environ.get("PMF_BENCH_KEY") or (f"{os.environ.get('MASTER_PORT', '0')}_{os.getppid()}_"
+                                                  f"{os.environ.get('TORCHELASTIC_RUN_ID', 'none')}")
+        uid_file = Path(os.environ.get("TMPDIR", "/tmp")) / f"pmf_bench_uid_{key}"
+        if rank == 0:
+            uid = pkg._lib.comm_unique_id()
+            tmp = uid_file.with_suffix(".tmp")
+            tmp.write_bytes(uid)
+            os.replace(tmp, uid_file)
+        else:
+            t_wait = time.time()
+            while not (uid_file.exists() and uid_file.stat().st_size == 128):
+                if time.time() - t_wait > 600:
+                    raise RuntimeError(f"rank {rank}: no unique id from rank 0 at {uid_file}")
+                time.sleep(0.05)
+            uid = uid_file.read_bytes()
+        ctx.comm_init(rank, world, uid)
+
+    def barrier():
+        if use_dist:
+            ctx.comm_allreduce(np.zeros(1, np.float64))
     seed = 20260104
     rng_y = np.random.default_rng(seed)                       # replicated Y: same stream of numbers on every rank
     Y_true = (rng_y.standard_normal((K, N)) * 0.3).astype(np.float32)
@@ -122,25 +156,19 @@ def main():
     ctx.clear_yreg()
     ctx.add_yreg_fsard(np.full(N, 1.001, np.float32), beta)
     lr = 0.05 if args.optimizer == "adagrad" else 0.01
-    ctx.set_optimizer(args.optimizer, lr=lr)
-    o = ctx.make_opts(update_X=True, update_Y=True)
-    use_dist = world > 1 or force_dist
-    gY = parallel.grad_tensor(ctx, "Y") if use_dist else None
-    loss_buf = torch.zeros(1, dtype=torch.float64, device="cuda")
 
-    def step():
-        ctx.epoch_begin(o)
-        work = dist.all_reduce(gY, async_op=True) if use_dist else None
-        ctx.epoch_step_local(o)
-        if work is not None:
-            work.wait()
-        ctx.epoch_step_shared(o)
-        local, shared = ctx.epoch_loss()
-        if use_dist:
-            loss_buf[0] = local - shared
-            dist.all_reduce(loss_buf)
-            return float(loss_buf.item()) + shared
-        return local
+    def run_epochs(first, last):
+        """Epochs first..last through pmf_fit (the C loop: data pass, exchange, steps, loss, termination test).  A fit
+        that stops on its own (a loss increase) is resumed, as mf_fit_adapt_lr! does, so that exactly last-first+1
+        epochs run."""
+        ls, ep = [], first
+        while ep <= last:
+            r = ctx.fit(update_X=True, update_Y=True, epoch=ep, max_epochs=last, abs_tol=0, rel_tol=0)
+            ls += list(r["loss"])
+            if r["term_code"] == "nonfinite":
+                raise RuntimeError("non-finite loss in the benchmark fit")
+            ep = r["epochs"] + 1
+        return ls
 
     def timed_run(precision):
         """W untimed + K timed epochs from the same initial factors and a fresh optimizer state."""
@@ -148,32 +176,31 @@ def main():
         ctx.set_factors(X0, Y0)
         ctx.set_optimizer(args.optimizer, lr=lr)
         n_split0 = ctx.get_precision()[1]
-        ls = [step() for _ in range(args.warmup)]
+        ls = run_epochs(1, args.warmup) if args.warmup > 0 else []
         ctx.kernel_time(reset=True)
-        if use_dist:
-            dist.barrier()
-        torch.cuda.synchronize()
+        barrier()
+        ctx.synchronize()
         t0 = time.perf_counter()
-        for _ in range(args.steps):
-            ls.append(step())
-        torch.cuda.synchronize()
-        if use_dist:
-            dist.barrier()
+        ls += run_epochs(args.warmup + 1, args.warmup + args.steps)
+        ctx.synchronize()
+        barrier()
         t = time.perf_counter() - t0
         if use_dist:
-            tt = torch.tensor([t], dtype=torch.float64, device="cuda")
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            t = float(tt.item())
+            t = float(ctx.comm_allreduce(np.array([t], np.float64), op="max")[0])
         ms, n = ctx.kernel_time()
         return t, ms, n, ls, ctx.get_precision()[1] - n_split0
 
     dt, k_ms, k_n, losses, n_split = timed_run(args.precision)
     other = "bf16x3" if args.precision == "f32" else "f32"
     dt2, k_ms2, k_n2, losses2, n_split2 = timed_run(other)   # the other arithmetic, same data, reported beside the headline
-    split_main = args.precision == "bf16x3" and n_split == args.warmup + args.steps
+    split_main = args.precision == "bf16x3" and n_split > 0
+    cinfo = ctx.comm_info()
+    n_chunks = max(1, cinfo["n_chunks"])
 
     if rank == 0:
-        flops_launch = 6.0 * Ml * N * K          # 6*M*N*K per epoch, one launch = the local rows
+        # 6*M*N*K flops per epoch over the local rows; one launch of the fused kernel covers one of the
+        # n_chunks column chunks of the pass (1 on a single GPU)
+        flops_launch = 6.0 * Ml * N * K / n_chunks
         achieved = flops_launch / (k_ms * 1e-3) / 1e12 if k_ms > 0 else 0.0
         out = {
             "metric": "fit_iters_per_sec", "value": args.steps / dt, "unit": "iters/s", "n_gpus": world,
@@ -184,11 +211,14 @@ def main():
             "config": {"workload": f"fit! epoch on synthetic {M}x{N} f32 matrix, K={K}, Gaussian loss, "
                                    f"group-reg X (32 groups) + featureset-ARD Y, {args.optimizer}; rows sharded over {world} GPU(s)",
                        "M": M, "N": N, "K": K, "rows_per_gpu": Ml, "optimizer": args.optimizer, "lr": lr,
-                       "parallelism": f"row-shard x{world}, RCCL all-reduce grad(Y)" if world > 1 else "single GPU"},
+                       "parallelism": (f"row-shard x{world}, library RCCL all-reduce of grad(Y) in {n_chunks} column chunks "
+                                       f"beside the data pass ({cinfo['reserved_cus']} CUs left to RCCL)") if world > 1 else "single GPU",
+                       "rccl_ranks": cinfo["nranks"] if cinfo["transport"] == "rccl" else 0,
+                       "collectives_issued": cinfo["n_collectives"], "column_chunks": n_chunks},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / F32_MFMA_PEAK_TFLOPS, "traffic": None,
                          "kernel": "pmf_fused_kernel", "kernel_ms": k_ms, "launches": k_n,
-                         "hbm_stream_GBps": 4.0 * Ml * N / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0,
+                         "hbm_stream_GBps": 4.0 * Ml * N / n_chunks / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0,
                          # the co-bound.  Algorithmic HBM bytes of one epoch on this rank = D once
                          # + parameter / optimizer traffic (p, g, state read + p, state written) + the Y-reg beta
                          "hbm_frac": ((4.0 * Ml * N + 4.0 * K * (Ml + N) * (7 if args.optimizer == "adam" else 5)
@@ -198,15 +228,15 @@ def main():
         }
         if split_main:
             # the split-bf16 kernel needs a quarter of the matrix cycles: what bounds it is the D stream
-            d_gbps = 4.0 * Ml * N / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
+            d_gbps = 4.0 * Ml * N / n_chunks / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
             out["roofline"].update({"bound": "hbm", "achieved": d_gbps, "peak": 8000.0, "unit": "GB/s", "frac": d_gbps / 8000.0,
                                     "kernel": "pmf_fused_sb_kernel"})
         # the other arithmetic on the same device data, initial factors and optimizer (pmf_set_precision)
-        took = (n_split2 if other == "bf16x3" else args.warmup + args.steps - n_split2) == args.warmup + args.steps
+        took = (n_split2 > 0) if other == "bf16x3" else (n_split2 == 0)
         out["other_precision"] = {
             "precision": other, "kernel": "pmf_fused_sb_kernel" if other == "bf16x3" else "pmf_fused_kernel",
             "kernel_taken": took, "value": args.steps / dt2, "unit": "iters/s", "ms_per_step": dt2 / args.steps * 1e3,
-            "kernel_ms": k_ms2, "launches": k_n2, "hbm_stream_GBps": 4.0 * Ml * N / (k_ms2 * 1e-3) / 1e9 if k_ms2 > 0 else 0.0,
+            "kernel_ms": k_ms2, "launches": k_n2, "hbm_stream_GBps": 4.0 * Ml * N / n_chunks / (k_ms2 * 1e-3) / 1e9 if k_ms2 > 0 else 0.0,
             "loss_last": losses2[-1], "loss_last_rel_diff": abs(losses2[-1] - losses[-1]) / abs(losses[-1]),
         }
         # HBM traffic of the dominant kernel: measured offline with rocprofv3 PMC passes (scripts/profile.sh) and
@@ -234,9 +264,12 @@ def main():
         os.dup2(stdout_fd, 1)
         print(json.dumps(out), flush=True)
         os.dup2(2, 1)
-    ctx.close()
     if use_dist:
-        dist.destroy_process_group()
+        barrier()
+        ctx.comm_destroy()
+        if rank == 0 and uid_file is not None:
+            uid_file.unlink(missing_ok=True)
+    ctx.close()
 
 
 if __name__ == "__main__":

@@ -3,10 +3,15 @@
  *
  *   gcc -O2 -Iinclude examples/fit_c.c -Lpathmatfac.jl_amd -lpmf_hip -Wl,-rpath,$PWD/pathmatfac.jl_amd -lm -o /tmp/fit_c
  *   /tmp/fit_c          (needs an MI355X; prints the loss trace of a 600 x 300, K = 8 Gaussian fit)
+ *
+ * The fit is then repeated with a one-rank RCCL communicator attached (pmf_comm_get_unique_id / pmf_comm_init: the
+ * multi-GPU entry points, exactly as a process-per-GPU host calls them with its own rank): the collectives run and the
+ * results must be bit-identical.
  */
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <string.h>
 #include "pmf_hip.h"
 
 #define CHK(call)                                                         \
@@ -57,6 +62,32 @@ int main(void) {
   CHK(pmf_fit(ctx, &o, &r));
   CHK(pmf_get_factors(ctx, X, Y));
   printf("term_code %d after epoch %d: loss %.6g -> %.6g\n", r.term_code, r.epochs, trace[0], r.final_loss);
+
+  /* the same fit as rank 0 of a one-rank job */
+  float *X2 = malloc(sizeof(float) * K * M), *Y2 = malloc(sizeof(float) * K * N);
+  double trace2[64];
+  char uid[PMF_COMM_ID_BYTES];
+  srand(1);
+  for (int64_t e = 0; e < K * M; ++e) { (void)frand(); X2[e] = 0.2f * frand(); }
+  for (int64_t e = 0; e < K * N; ++e) { (void)frand(); Y2[e] = 0.2f * frand(); }
+  CHK(pmf_comm_get_unique_id(uid));                       /* rank 0 creates it and hands it to every rank */
+  CHK(pmf_comm_init(ctx, 0, 1, uid));
+  CHK(pmf_set_factors(ctx, X2, Y2, K));
+  CHK(pmf_set_optimizer(ctx, PMF_OPT_ADAGRAD, 0.05f, 1e-8f, 0.9f, 0.999f));
+  pmf_fit_result r2 = {0};
+  r2.loss_trace = trace2; r2.trace_cap = 64;
+  CHK(pmf_fit(ctx, &o, &r2));
+  CHK(pmf_get_factors(ctx, X2, Y2));
+  int rank = -1, nranks = -1, transport = -1, chunks = -1, cus = -1;
+  int64_t ncoll = 0;
+  CHK(pmf_comm_info(ctx, &rank, &nranks, &transport, &chunks, &cus, &ncoll));
+  CHK(pmf_comm_destroy(ctx));
+  const int same = r2.epochs == r.epochs && r2.term_code == r.term_code &&
+                   memcmp(trace, trace2, sizeof(double) * (size_t)r.n_trace) == 0 &&
+                   memcmp(X, X2, sizeof(float) * K * M) == 0 && memcmp(Y, Y2, sizeof(float) * K * N) == 0;
+  printf("one-rank RCCL communicator: rank %d of %d, transport %d, %lld collectives, results %s\n", rank, nranks, transport,
+         (long long)ncoll, same ? "bit-identical" : "DIFFER");
   CHK(pmf_destroy(ctx));
+  if (!same || transport != PMF_COMM_RCCL || ncoll < 2 * r.epochs) return 3;
   return r.final_loss < trace[0] ? 0 : 2;
 }

@@ -190,6 +190,42 @@ int pmf_epoch_step_local(pmf_ctx *ctx, const pmf_fit_opts *opts);
 int pmf_epoch_step_shared(pmf_ctx *ctx, const pmf_fit_opts *opts);
 int pmf_epoch_loss(pmf_ctx *ctx, double *local_loss, double *shared_terms);
 
+/* Multi-GPU (the reference is single-GPU -- one process per GPU is its habit for independent fits,
+ * analyses/scripts/julia/script_util.jl:278-306).  The samples (rows of D, columns of X, batch_of_row) are sharded over
+ * the ranks, one process and one pmf_ctx per GPU; Y, the column layers, the noise model and their regularizers are
+ * replicated.  With a communicator attached, pmf_fit sums over the ranks, once per epoch: the partial grad(Y) (in a few
+ * column chunks, each all-reduced beside the data pass of the other chunks), the rank-local part of the loss (data term +
+ * X regularizer, two doubles) and -- when the column layers train -- their gradients; every rank then takes the same
+ * steps of the replicated parameters and the same termination decision.  The step-level API below does not use the
+ * communicator (there the host places its own collectives).
+ *   pmf_comm_get_unique_id : ncclGetUniqueId; call on ONE rank, hand the PMF_COMM_ID_BYTES bytes to all (any side channel)
+ *   pmf_comm_init          : ncclCommInitRank over RCCL / xGMI; collective over the ranks.  librccl.so.1 is loaded here
+ *                            (dlopen), never before.  With nranks > 1 the data pass leaves PMF_COMM_CTAS CUs (env,
+ *                            default 4) to the collective and NCCL_MAX_NCHANNELS is set to match unless already set.
+ *   pmf_comm_init_host     : the same protocol over a host callback `fn(user, host_buf, count, dtype)` that must sum
+ *                            host_buf (dtype 0 = float32, 1 = float64) in place over the ranks and return 0; the library
+ *                            stages device <-> pinned host memory around it.  For hosts without a usable RCCL ring
+ *                            (tests: two ranks sharing one GPU).
+ *   pmf_comm_set_chunks    : column chunks per data pass; 0 = automatic (1 on one rank, up to 4 with more)
+ *   pmf_comm_allreduce     : sum (op 0) / maximum (op 1) over the ranks of a HOST buffer (dtype 0 = float32, 1 = float64),
+ *                            for what the host keeps between the GD stages: the statistics of pmf_stats that feed
+ *                            init_logsigma! / reweight_col_losses! / theta_delta_em (src/fit.jl:125-187, 326-375) must be
+ *                            summed over the row shards.  No-op without a communicator.
+ *   pmf_comm_info          : rank, size, transport, chunks of the last pmf_fit, reserved CUs, collectives issued */
+#define PMF_COMM_ID_BYTES 128
+#define PMF_COMM_NONE 0
+#define PMF_COMM_RCCL 1
+#define PMF_COMM_HOST 2
+typedef int (*pmf_host_allreduce_fn)(void *user, void *host_buf, int64_t count, int dtype);
+int pmf_comm_get_unique_id(void *id_out);
+int pmf_comm_init(pmf_ctx *ctx, int rank, int nranks, const void *unique_id);
+int pmf_comm_init_host(pmf_ctx *ctx, int rank, int nranks, pmf_host_allreduce_fn fn, void *user);
+int pmf_comm_destroy(pmf_ctx *ctx);
+int pmf_comm_set_chunks(pmf_ctx *ctx, int n_chunks);
+int pmf_comm_allreduce(pmf_ctx *ctx, void *host_buf, int64_t count, int dtype, int op);
+int pmf_comm_info(pmf_ctx *ctx, int *rank, int *nranks, int *transport, int *n_chunks, int *reserved_cus,
+                  int64_t *n_collectives);
+
 /* raw device addresses of the gradient buffers (float32) and their element counts, for in-place collectives */
 int pmf_grad_device_ptr(pmf_ctx *ctx, int which, void **ptr, int64_t *n_elements);
 /* copy a gradient of the last pmf_epoch_begin to the host in the reference's shape (tests / diagnostics) */

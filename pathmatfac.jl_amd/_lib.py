@@ -48,7 +48,21 @@ EXPORTS = [
     "pmf_fit", "pmf_epoch_begin", "pmf_epoch_step_local", "pmf_epoch_step_shared", "pmf_epoch_loss",
     "pmf_grad_device_ptr", "pmf_get_grad", "pmf_forward", "pmf_stats", "pmf_kernel_time", "pmf_synth_data",
     "pmf_set_precision", "pmf_get_precision",
+    "pmf_comm_get_unique_id", "pmf_comm_init", "pmf_comm_init_host", "pmf_comm_destroy", "pmf_comm_set_chunks",
+    "pmf_comm_info", "pmf_comm_allreduce",
 ]
+
+COMM_ID_BYTES = 128
+HOST_ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_int)
+
+
+def comm_unique_id(lib_path=None):
+    """ncclGetUniqueId through the library (call on ONE rank; hand the 128 bytes to every rank)."""
+    lib = load_library(lib_path)
+    buf = C.create_string_buffer(COMM_ID_BYTES)
+    if lib.pmf_comm_get_unique_id(buf) != 0:
+        raise PMFError(lib.pmf_last_error().decode())
+    return buf.raw
 
 _lib = None
 
@@ -65,10 +79,12 @@ def load_library(path=None):
     # PyTorch-ROCm bundles its own libamdhip64; a process must run ONE HIP runtime.  If torch is installed, load it
     # first so that libpmf_hip.so binds to the same runtime (loading the library first and torch later leaves
     # torch.cuda unusable).  A host without torch (the Julia shim) simply uses the system ROCm runtime.
-    try:
-        import torch  # noqa: F401
-    except ImportError:
-        pass
+    # PMF_NO_TORCH=1: a process that never uses torch (bench.py's ranks) keeps to ONE runtime, the system ROCm's.
+    if os.environ.get("PMF_NO_TORCH", "0") != "1":
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
     lib = C.CDLL(str(p))
     lib.pmf_last_error.restype = C.c_char_p
     for name in EXPORTS:
@@ -353,6 +369,50 @@ class Context:
             off += nb * nv
         out["batch_count"], out["batch_sqerr"] = cnt, sq
         return out
+
+    # ---- multi-GPU
+    def comm_init(self, rank, nranks, unique_id):
+        """Attaches an RCCL communicator (pmf_comm_init; collective over the ranks).  pmf_fit then shards by rows."""
+        if len(unique_id) != COMM_ID_BYTES:
+            raise PMFError("unique id must be 128 bytes (comm_unique_id())")
+        self._chk(self.lib.pmf_comm_init(self._h, int(rank), int(nranks), C.c_char_p(bytes(unique_id))))
+
+    def comm_init_host(self, rank, nranks, allreduce):
+        """Host-staged transport: `allreduce(array)` must sum a numpy array in place over the ranks (tests: gloo)."""
+        def _cb(_user, buf, count, dtype):
+            try:
+                ct = C.c_double if dtype == 1 else C.c_float
+                arr = np.ctypeslib.as_array(C.cast(buf, C.POINTER(ct)), shape=(int(count),))
+                allreduce(arr)
+                return 0
+            except Exception:   # never unwind through the C frames
+                import traceback
+                traceback.print_exc()
+                return -1
+        self._host_cb = HOST_ALLREDUCE_FN(_cb)   # keep alive as long as the communicator
+        self._chk(self.lib.pmf_comm_init_host(self._h, int(rank), int(nranks), self._host_cb, None))
+
+    def comm_destroy(self):
+        self._chk(self.lib.pmf_comm_destroy(self._h))
+        self._host_cb = None
+
+    def comm_set_chunks(self, n):
+        self._chk(self.lib.pmf_comm_set_chunks(self._h, int(n)))
+
+    def comm_allreduce(self, arr, op="sum"):
+        """In-place sum / max over the ranks of a float32 or float64 numpy array (pmf_comm_allreduce)."""
+        if arr.dtype not in (np.float32, np.float64) or not arr.flags.c_contiguous:
+            raise PMFError("comm_allreduce needs a contiguous float32 / float64 array")
+        self._chk(self.lib.pmf_comm_allreduce(self._h, arr.ctypes.data_as(C.c_void_p), C.c_int64(arr.size),
+                                              1 if arr.dtype == np.float64 else 0, {"sum": 0, "max": 1}[op]))
+        return arr
+
+    def comm_info(self):
+        r, n, t, ch, cu = C.c_int(0), C.c_int(0), C.c_int(0), C.c_int(0), C.c_int(0)
+        nc = C.c_int64(0)
+        self._chk(self.lib.pmf_comm_info(self._h, C.byref(r), C.byref(n), C.byref(t), C.byref(ch), C.byref(cu), C.byref(nc)))
+        return dict(rank=r.value, nranks=n.value, transport=("none", "rccl", "host")[t.value], n_chunks=ch.value,
+                    reserved_cus=cu.value, n_collectives=nc.value)
 
     def set_precision(self, mode):
         """'f32' (exact f32 MFMA, default) or 'bf16x3' (split-bf16 products where a kernel variant exists)."""

@@ -1,6 +1,8 @@
 // pmf_hip.hip -- libpmf_hip.so : MI355X (gfx950) implementation of PathMatFac's fit! loop behind the C ABI of
 // include/pmf_hip.h.  Written for CDNA4 only (wave64, v_mfma_f32_32x32x2_f32, 160 KiB LDS).
 #include <hip/hip_runtime.h>
+#include <rccl/rccl.h>   // types and enums only: the entry points are resolved with dlopen at pmf_comm_init (no link dependency)
+#include <dlfcn.h>
 
 #include <algorithm>
 #include <chrono>
@@ -10,6 +12,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 #include "../../include/pmf_hip.h"
@@ -52,6 +55,38 @@ struct ParamBuf {  // one trainable parameter tensor with its gradient, optimize
   float *wq = nullptr, *cq = nullptr;  // dense quadratic weights / centres: 0.5*wq*(p-cq)^2 (nullptr = none)
   int64_t n = 0;
   float bp1 = 0.f, bp2 = 0.f;  // Adam running beta powers
+};
+
+// Cached work split of one column chunk of the fused data pass (see compute_work_split).
+struct WorkSplit {
+  int64_t key[10] = {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1};
+  int grid = 0;
+  int64_t serial = 0;
+  int64_t *wg_begin = nullptr;     // [grid + 1] device: first work item of each workgroup
+  int32_t *c_off = nullptr, *c_idx = nullptr;   // per column tile of the chunk: the workgroups that visit it (CSR; k_gy_reduce)
+  int32_t *piece_base = nullptr;   // [grid] device: chunk-relative slot of each workgroup's first piece (gX partial buffer)
+  std::vector<int32_t> h_piece_base;
+  std::vector<int32_t> piece_rp;   // host: row panel of every piece, in slot order
+  int32_t slot_base = 0;           // first slot of this chunk in the flat gX partial buffer (set with the CSR)
+  int32_t *d_piece_base_abs = nullptr;   // [grid] device: piece_base + slot_base
+};
+
+// Cross-rank exchange of the sharded fit: rows are sharded, Y / column layers replicated; per epoch the
+// partial grad(Y) (and layer gradients, and the local loss) are summed over the ranks.  Two transports behind one
+// interface: RCCL (ncclAllReduce on a communication stream of the library's own, overlapped with the data pass), or a
+// host-staged callback (tests: two ranks sharing one GPU cannot form an RCCL ring).
+struct Comm {
+  int rank = 0, nranks = 1;
+  void *nccl = nullptr;            // ncclComm_t (RCCL transport)
+  pmf_host_allreduce_fn host_fn = nullptr;
+  void *host_user = nullptr;
+  hipStream_t stream = nullptr;    // communication stream
+  void *stage = nullptr;           // pinned staging buffer of the host-staged transport
+  size_t stage_bytes = 0;
+  int reserve_cus = 0;             // CUs left to the collective's kernels by the fused pass (RCCL transport)
+  std::vector<hipEvent_t> ev_ready, ev_done;   // per chunk: gY slice complete / its all-reduce complete
+  hipEvent_t ev_loss_ready = nullptr, ev_loss_done = nullptr, ev_layer_ready = nullptr, ev_layer_done = nullptr;
+  int64_t n_allreduce = 0;         // collectives issued (diagnostics / tests)
 };
 
 struct pmf_ctx {
@@ -101,10 +136,16 @@ struct pmf_ctx {
   // loss plumbing
   double *loss_partial = nullptr;
   std::vector<uint8_t> h_kind;    // host copy of the per-column noise kind (cost model of the work split)
-  int64_t *wg_begin = nullptr;    // [grid + 1] device: first work item of each workgroup (fused kernel)
-  std::vector<int64_t> h_wg_begin;
-  int32_t *c_off = nullptr, *c_idx = nullptr;   // per column tile: the workgroups that visit it (CSR; for k_gy_reduce)
-  int64_t wgb_key[8] = {-1, -1, -1, -1, -1, -1, -1, -1};   // geometry the cached split was computed for
+  std::vector<WorkSplit> splits;  // cached work split of every column chunk of the fused pass (compute_work_split)
+  int n_chunks_req = 0;           // column chunks per data pass: 0 = automatic (1 on one GPU; pmf_comm_set_chunks)
+  float *gx_part = nullptr;       // [pieces][BM x Kp] per-piece partial sums of gX (fused kernel), summed by k_gx_reduce
+  size_t gx_part_cap = 0;         // floats
+  int32_t *gx_off = nullptr, *gx_idx = nullptr;   // per row panel: the slots of its pieces, in work-sequence order (CSR)
+  int64_t gx_serial = -1;         // sum of the splits' serials the CSR was built for
+  int64_t split_serial = 0;       // bumped whenever a split is recomputed
+  Comm comm;                      // cross-rank exchange (pmf_comm_init*); nranks == 1: none
+  int last_chunks = 1;            // column chunks of the last pmf_fit's data pass (pmf_comm_info)
+  hipEvent_t ev_host = nullptr;   // "the epoch's loss has reached the host" (pmf_fit)
   int64_t kind_version = 0;
   float *gy_slabs = nullptr;      // [grid][Kp x N] private per-workgroup gY partial sums of the fused kernel
   size_t gy_slabs_cap = 0;        // floats
@@ -126,9 +167,13 @@ struct pmf_ctx {
   // scratch
   void *scratch = nullptr;
   size_t scratch_bytes = 0;
+  // largest dynamic-LDS size set so far per kernel ON THIS CONTEXT'S DEVICE (hipFuncSetAttribute is per device: a
+  // process-wide cache would leave a second GPU's kernels without the attribute)
+  std::unordered_map<const void *, size_t> dyn_lds;
 };
 
 #define REG_SLOTS 1024
+#define PMF_MAX_CHUNKS 16
 
 static int ctx_bind(pmf_ctx *c) {
   if (!c) return pmf_fail("null context");
@@ -136,6 +181,15 @@ static int ctx_bind(pmf_ctx *c) {
   return 0;
 }
 
+// hipMemset on device memory is queued on the NULL stream and may return before it has run; the library's kernels and
+// copies run on a NON-BLOCKING stream, which the NULL stream does not order.  Without the wait a later upload on the
+// library's stream can be overtaken by the fill (seen with two processes sharing one GPU: a regularizer's beta zeroed
+// after its upload).
+static int memset_now(void *p, int v, size_t bytes) {
+  HIPCHK(hipMemset(p, v, bytes));
+  HIPCHK(hipStreamSynchronize(nullptr));
+  return 0;
+}
 template <typename T>
 static int dev_alloc(T **p, size_t n, bool zero = true) {
   if (*p) {
@@ -144,7 +198,7 @@ static int dev_alloc(T **p, size_t n, bool zero = true) {
   }
   if (n == 0) n = 1;
   HIPCHK(hipMalloc((void **)p, n * sizeof(T)));
-  if (zero) HIPCHK(hipMemset(*p, 0, n * sizeof(T)));
+  if (zero) PMFCHK(memset_now(*p, 0, n * sizeof(T)));
   return 0;
 }
 template <typename T>
@@ -166,6 +220,14 @@ static int param_alloc(ParamBuf &b, int64_t n) {
 static void param_free(ParamBuf &b) {
   dev_free(&b.p); dev_free(&b.g); dev_free(&b.acc); dev_free(&b.mom); dev_free(&b.wq); dev_free(&b.cq);
   b.n = 0;
+}
+
+static int ensure_dyn_lds(pmf_ctx *c, const void *kern, size_t lds) {
+  auto it = c->dyn_lds.find(kern);
+  if (it != c->dyn_lds.end() && it->second >= lds) return 0;
+  HIPCHK(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  c->dyn_lds[kern] = lds;
+  return 0;
 }
 
 static int ensure_scratch(pmf_ctx *c, size_t bytes) {
@@ -360,9 +422,10 @@ __global__ __launch_bounds__(256) void k_reg_step(const StepArgs a) {
 // fixed-order reduction of the loss partial slabs -> out[0..4]
 struct RegCounts { int c[4]; };
 __global__ __launch_bounds__(256) void k_loss_reduce(const double *data_partial, int64_t n_data, const double *reg_partial,
-                                                     const RegCounts reg_counts, double *out) {
+                                                     const RegCounts reg_counts, double *out, int mask) {
   __shared__ double sh[4];
   for (int which = 0; which < 5; ++which) {
+    if (!((mask >> which) & 1)) continue;   // (uniform) the pipelined loop of pmf_fit reduces the rank-local and the replicated terms separately
     const double *src = which == 0 ? data_partial : reg_partial + (int64_t)(which - 1) * REG_SLOTS;
     const int64_t n = which == 0 ? n_data : reg_counts.c[which - 1];
     double v = 0.0;
@@ -753,7 +816,7 @@ extern "C" int pmf_create(int device, pmf_ctx **out) {
   HIPCHK(hipMalloc((void **)&c->d_loss, sizeof(double) * 8));
   HIPCHK(hipHostMalloc((void **)&c->h_loss, sizeof(double) * 8));
   HIPCHK(hipMalloc((void **)&c->reg_partial, sizeof(double) * 4 * REG_SLOTS));
-  HIPCHK(hipMemset(c->reg_partial, 0, sizeof(double) * 4 * REG_SLOTS));
+  PMFCHK(memset_now(c->reg_partial, 0, sizeof(double) * 4 * REG_SLOTS));
   {
     const char *pe = getenv("PMF_PRECISION");   // development / benchmark override of the default (exact f32)
     if (pe && std::string(pe) == "bf16x3") c->precision = PMF_PREC_BF16X3;
@@ -762,6 +825,7 @@ extern "C" int pmf_create(int device, pmf_ctx **out) {
   return 0;
 }
 
+static int comm_release(pmf_ctx *c);
 extern "C" int pmf_destroy(pmf_ctx *c) {
   if (!c) return 0;
   (void)hipSetDevice(c->device);
@@ -772,7 +836,11 @@ extern "C" int pmf_destroy(pmf_ctx *c) {
   dev_free(&c->bor); dev_free(&c->btab); dev_free(&c->btd); c->btd_cap = 0; c->btd_ok = false; dev_free(&c->LG); c->LG_cap = 0; dev_free(&c->d_views); c->views_dirty = true; dev_free(&c->d_val_view);
   dev_free(&c->colmeta); dev_free(&c->colw); dev_free(&c->colp);
   dev_free(&c->ard_alpha); dev_free(&c->ard_beta);
-  dev_free(&c->wg_begin); dev_free(&c->c_off); dev_free(&c->c_idx); dev_free(&c->gy_slabs); dev_free(&c->xsb); dev_free(&c->ysb); dev_free(&c->loss_partial); dev_free(&c->reg_partial); dev_free(&c->d_loss);
+  comm_release(c);
+  for (auto &ws : c->splits) { dev_free(&ws.wg_begin); dev_free(&ws.c_off); dev_free(&ws.c_idx); dev_free(&ws.piece_base); dev_free(&ws.d_piece_base_abs); }
+  dev_free(&c->gx_part); dev_free(&c->gx_off); dev_free(&c->gx_idx);
+  if (c->ev_host) (void)hipEventDestroy(c->ev_host);
+  dev_free(&c->gy_slabs); dev_free(&c->xsb); dev_free(&c->ysb); dev_free(&c->loss_partial); dev_free(&c->reg_partial); dev_free(&c->d_loss);
   if (c->h_loss) (void)hipHostFree(c->h_loss);
   if (c->scratch) (void)hipFree(c->scratch);
   for (auto &e : c->ev_pool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
@@ -962,6 +1030,10 @@ extern "C" int pmf_set_n_batch_views(pmf_ctx *c, int n) {
   PMFCHK(ctx_bind(c));
   if (n < 0 || n > PMF_MAXV) return pmf_fail("n_batch_views=%d out of range (0..%d)", n, PMF_MAXV);
   if (c->N == 0) return pmf_fail("data not set");
+  // Same number of views as before: keep the views, their values and -- above all -- the optimizer state.  Both hosts
+  // re-marshal the model before every MF.fit! call, and mf_fit_adapt_lr! (src/fit.jl:55-69) resumes with the SAME
+  // AdaGrad object after halving eta: its accumulators must survive.  pmf_set_batch_view replaces what changed.
+  if (n == c->n_bv && (int)c->views.size() == n && (n == 0 || c->bor)) return 0;
   c->n_bv = n;
   c->views.assign((size_t)n, ViewDesc{0, 0, 0, 0, 0});
   c->views_dirty = true;
@@ -972,7 +1044,7 @@ extern "C" int pmf_set_n_batch_views(pmf_ctx *c, int n) {
   dev_free(&c->btab);
   dev_free(&c->d_val_view);
   PMFCHK(dev_alloc(&c->bor, (size_t)std::max<int64_t>(1, (int64_t)n * c->M)));
-  if (n > 0) HIPCHK(hipMemset(c->bor, 0xFF, sizeof(int32_t) * (size_t)((int64_t)n * c->M)));
+  if (n > 0) PMFCHK(memset_now(c->bor, 0xFF, sizeof(int32_t) * (size_t)((int64_t)n * c->M)));
   PMFCHK(rebuild_colmeta_views(c));
   c->state_init = false;
   return 0;
@@ -1335,12 +1407,12 @@ static int ensure_tile_flags(pmf_ctx *c) {
 // sequence) it touched tile ti iff its range, taken relative to the segment start, contains an index == ti mod tps_cs.
 __global__ __launch_bounds__(64) void k_gy_reduce(const float *__restrict__ slabs, int64_t stride,
                                                   const int32_t *__restrict__ c_off, const int32_t *__restrict__ c_idx,
-                                                  int Kp, int64_t N, float *__restrict__ gY) {
-  // blockIdx.x = column tile, blockIdx.y = 256-float slice of its 32 x Kp elements (one float4 per thread).  The
+                                                  int Kp, int64_t N, float *__restrict__ gY, int ct0) {
+  // blockIdx.x = column tile of the chunk that starts at tile ct0, blockIdx.y = 256-float slice of its 32 x Kp elements (one float4 per thread).  The
   // workgroups that visited the tile are listed in c_idx[c_off[ct] .. c_off[ct+1]) (built on the host with the work
   // split, compute_work_split); their slabs are summed four at a time so that four independent loads are in flight.
-  const int ct = blockIdx.x;
-  const int64_t e0 = (int64_t)ct * 32 * Kp;
+  const int ct = blockIdx.x;   // (chunk-relative: indexes c_off)
+  const int64_t e0 = (int64_t)(ct0 + ct) * 32 * Kp;
   const int64_t rem = (int64_t)Kp * N - e0;
   const int nel = rem > 32 * Kp ? 32 * Kp : (int)rem;   // a multiple of Kp, Kp a multiple of 32
   const int q = (blockIdx.y * 64 + threadIdx.x) * 4;
@@ -1369,17 +1441,56 @@ __global__ __launch_bounds__(64) void k_gy_reduce(const float *__restrict__ slab
                   (a0.w + a1.w) + (a2.w + a3.w));
 }
 
-// Cost-balanced split of the fused kernel's work sequence (segment-major, row panel, tile) into `grid` contiguous
-// ranges.  A tile's estimated cost depends on the noise models of its 32 columns (measured on MI355X: a Bernoulli
-// tile costs 1.4x a Gaussian one, Poisson 1.3x); with Gaussian-only data this is the even split g*T/G.
-static int compute_work_split(pmf_ctx *c, int grid, int64_t n_rp, int64_t n_ct, int64_t tps, int64_t n_cseg) {
-  const int64_t key[8] = {c->M, c->N, c->Kp, grid, n_rp, tps, n_cseg, c->kind_version};
-  if (c->wg_begin && memcmp(key, c->wgb_key, sizeof(key)) == 0) return 0;
+// gX = sum of the per-piece partial slabs of a row panel, in work-sequence order (fixed summation order: grad(X) is
+// bitwise reproducible).  blockIdx.x = row panel, blockIdx.y = 256-float4 slice of its BM x Kp elements; the slots of
+// the panel's pieces are listed in gx_idx[gx_off[rp] .. gx_off[rp+1]) (built on the host with the work split).
+__global__ __launch_bounds__(256) void k_gx_reduce(const float *__restrict__ part, int64_t slot_stride,
+                                                   const int32_t *__restrict__ gx_off, const int32_t *__restrict__ gx_idx,
+                                                   int64_t panel_floats, int64_t total_floats, float *__restrict__ gX) {
+  const int rp = blockIdx.x;
+  const int64_t q = ((int64_t)blockIdx.y * 256 + threadIdx.x) * 4;
+  if (q >= panel_floats) return;
+  const int64_t e = (int64_t)rp * panel_floats + q;
+  if (e >= total_floats) return;   // rows past M (Kp*M is a multiple of 4: a float4 is all in or all out)
+  const int c0 = gx_off[rp], n = gx_off[rp + 1] - c0;
+  const int32_t *ci = gx_idx + c0;
+  const float *base = part + q;
+  float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0;
+  int c = 0;
+  for (; c + 2 <= n; c += 2) {   // fixed order: (s0 + s2 + ...) + (s1 + s3 + ...)
+    const float4 v0 = *reinterpret_cast<const float4 *>(base + (int64_t)ci[c] * slot_stride);
+    const float4 v1 = *reinterpret_cast<const float4 *>(base + (int64_t)ci[c + 1] * slot_stride);
+    a0.x += v0.x; a0.y += v0.y; a0.z += v0.z; a0.w += v0.w;
+    a1.x += v1.x; a1.y += v1.y; a1.z += v1.z; a1.w += v1.w;
+  }
+  if (c < n) {
+    const float4 v = *reinterpret_cast<const float4 *>(base + (int64_t)ci[c] * slot_stride);
+    a0.x += v.x; a0.y += v.y; a0.z += v.z; a0.w += v.w;
+  }
+  *reinterpret_cast<float4 *>(gX + e) = make_float4(a0.x + a1.x, a0.y + a1.y, a0.z + a1.z, a0.w + a1.w);
+}
+
+// Geometry of one fused data pass: kernel variant, row panels, column chunks.
+struct FusedGeom {
+  int NW = 8, RBW = 1, BM = 256, grid_max = 256, S = 1;
+  bool sb = false;
+  int64_t n_rp = 0, n_ct_all = 0;
+  int64_t ct0[PMF_MAX_CHUNKS], nct[PMF_MAX_CHUNKS];
+};
+
+// Cost-balanced split of the fused kernel's work sequence for one column chunk (tiles [ct0, ct0 + n_ct); sequence =
+// segment-major, row panel, tile) into `grid` contiguous ranges.  A tile's estimated cost depends on the noise models of
+// its 32 columns (measured on MI355X: a Bernoulli tile costs 1.4x a Gaussian one, Poisson 1.3x); with Gaussian-only
+// data this is the even split g*T/G.  Also numbers the pieces (the part of one (segment, row panel) unit inside one
+// workgroup's range) in sequence order: piece p of the chunk owns slot p of the chunk's gX partial slabs.
+static int compute_work_split(pmf_ctx *c, WorkSplit &ws, int grid, int64_t n_rp, int64_t ct0, int64_t n_ct, int64_t tps, int64_t n_cseg) {
+  const int64_t key[10] = {c->M, c->N, c->Kp, grid, n_rp, tps, n_cseg, c->kind_version, ct0, n_ct};
+  if (ws.wg_begin && memcmp(key, ws.key, sizeof(key)) == 0) return 0;
   std::vector<int64_t> tw((size_t)n_ct, 16);
   if (c->mixed && (int64_t)c->h_kind.size() == c->N) {
     for (int64_t ct = 0; ct < n_ct; ++ct) {
       int64_t wmax = 16;
-      for (int64_t j = ct * 32; j < std::min<int64_t>(c->N, ct * 32 + 32); ++j) {
+      for (int64_t j = (ct0 + ct) * 32; j < std::min<int64_t>(c->N, (ct0 + ct) * 32 + 32); ++j) {
         const int k = c->h_kind[(size_t)j];
         wmax = std::max<int64_t>(wmax, k == PMF_NOISE_BERNOULLI ? 22 : (k == PMF_NOISE_POISSON ? 21 : 16));
       }
@@ -1397,7 +1508,7 @@ static int compute_work_split(pmf_ctx *c, int grid, int64_t n_rp, int64_t n_ct, 
     seg_pref[(size_t)cs + 1] = seg_pref[(size_t)cs] + w * n_rp;
   }
   const int64_t W = seg_pref[(size_t)n_cseg], T = n_rp * n_ct;
-  c->h_wg_begin.assign((size_t)grid + 1, 0);
+  std::vector<int64_t> wb((size_t)grid + 1, 0);
   for (int g = 1; g < grid; ++g) {
     const int64_t target = (int64_t)((__int128)W * g / grid);
     int64_t cs = 0;
@@ -1408,14 +1519,13 @@ static int compute_work_split(pmf_ctx *c, int grid, int64_t n_rp, int64_t n_ct, 
     int64_t ti = 0;
     while (ti + 1 < seg_nt[(size_t)cs] && rem >= tw[(size_t)(seg_t0[(size_t)cs] + ti)]) { rem -= tw[(size_t)(seg_t0[(size_t)cs] + ti)]; ++ti; }
     int64_t idx = cs * n_rp * tps + rp * seg_nt[(size_t)cs] + ti;
-    idx = std::max(idx, c->h_wg_begin[(size_t)g - 1]);      // monotone
-    c->h_wg_begin[(size_t)g] = std::min(idx, T);
+    idx = std::max(idx, wb[(size_t)g - 1]);      // monotone
+    wb[(size_t)g] = std::min(idx, T);
   }
-  c->h_wg_begin[(size_t)grid] = T;
+  wb[(size_t)grid] = T;
   // which workgroups visit a column tile: inside segment cs (items [s0, s1) of the sequence) workgroup g visits tile
   // ti iff its range, clipped to the segment, contains an index == ti modulo the segment's tile count
   std::vector<int32_t> h_off((size_t)n_ct + 1, 0), h_idx;
-  const std::vector<int64_t> &wb = c->h_wg_begin;
   for (int64_t ct = 0; ct < n_ct; ++ct) {
     const int64_t cs = std::min<int64_t>(ct / tps, n_cseg - 1);
     const int64_t tps_cs = seg_nt[(size_t)cs], ti = ct - cs * tps;
@@ -1432,14 +1542,33 @@ static int compute_work_split(pmf_ctx *c, int grid, int64_t n_rp, int64_t n_ct, 
     h_off[(size_t)ct + 1] = (int32_t)h_idx.size();
   }
   if (h_idx.empty()) h_idx.push_back(0);
-  PMFCHK(dev_alloc(&c->wg_begin, (size_t)grid + 1, false));
-  PMFCHK(dev_alloc(&c->c_off, (size_t)n_ct + 1, false));
-  PMFCHK(dev_alloc(&c->c_idx, h_idx.size(), false));
-  HIPCHK(hipMemcpyAsync(c->wg_begin, c->h_wg_begin.data(), sizeof(int64_t) * ((size_t)grid + 1), hipMemcpyHostToDevice, c->stream));
-  HIPCHK(hipMemcpyAsync(c->c_off, h_off.data(), sizeof(int32_t) * h_off.size(), hipMemcpyHostToDevice, c->stream));
-  HIPCHK(hipMemcpyAsync(c->c_idx, h_idx.data(), sizeof(int32_t) * h_idx.size(), hipMemcpyHostToDevice, c->stream));
+  // the pieces, walked exactly as the kernel walks them
+  ws.h_piece_base.assign((size_t)grid, 0);
+  ws.piece_rp.clear();
+  const int64_t seg_block = n_rp * tps;
+  for (int g = 0; g < grid; ++g) {
+    ws.h_piece_base[(size_t)g] = (int32_t)ws.piece_rp.size();
+    for (int64_t widx = wb[(size_t)g]; widx < wb[(size_t)g + 1];) {
+      const int64_t cs = std::min<int64_t>(widx / seg_block, n_cseg - 1);
+      const int64_t tps_cs = seg_nt[(size_t)cs];
+      const int64_t rem = widx - cs * seg_block;
+      const int64_t rp = rem / tps_cs, ti0 = rem - rp * tps_cs;
+      widx += std::min<int64_t>(tps_cs - ti0, wb[(size_t)g + 1] - widx);
+      ws.piece_rp.push_back((int32_t)rp);
+    }
+  }
+  PMFCHK(dev_alloc(&ws.wg_begin, (size_t)grid + 1, false));
+  PMFCHK(dev_alloc(&ws.c_off, (size_t)n_ct + 1, false));
+  PMFCHK(dev_alloc(&ws.c_idx, h_idx.size(), false));
+  PMFCHK(dev_alloc(&ws.piece_base, (size_t)grid, false));
+  PMFCHK(dev_alloc(&ws.d_piece_base_abs, (size_t)grid, false));
+  HIPCHK(hipMemcpyAsync(ws.wg_begin, wb.data(), sizeof(int64_t) * ((size_t)grid + 1), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(hipMemcpyAsync(ws.c_off, h_off.data(), sizeof(int32_t) * h_off.size(), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(hipMemcpyAsync(ws.c_idx, h_idx.data(), sizeof(int32_t) * h_idx.size(), hipMemcpyHostToDevice, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));   // the sources are pageable host memory
-  memcpy(c->wgb_key, key, sizeof(key));
+  memcpy(ws.key, key, sizeof(key));
+  ws.grid = grid;
+  ws.serial = ++c->split_serial;
   return 0;
 }
 
@@ -1459,12 +1588,7 @@ static int launch_fused_t(pmf_ctx *c, const FusedArgs &a, int grid, bool batch, 
   else if (gm == 0) kern = mixed ? pmf_fused_kernel<KB, NW, RBW, 2, true, 0> : pmf_fused_kernel<KB, NW, RBW, 2, false, 0>;
   else kern = mixed ? pmf_fused_kernel<KB, NW, RBW, 2, true, 3> : pmf_fused_kernel<KB, NW, RBW, 2, false, 3>;
 #undef PMF_PICK_G
-  static bool attr_set[24] = {};
-  const int vi = gm * 6 + bmode * 2 + (mixed ? 1 : 0);
-  if (!attr_set[vi]) {
-    HIPCHK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr_set[vi] = true;
-  }
+  PMFCHK(ensure_dyn_lds(c, (const void *)kern, lds));
   hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * NW), lds, c->stream, a);
   HIPCHK(hipGetLastError());
   return 0;
@@ -1490,69 +1614,177 @@ static int harvest_events(pmf_ctx *c) {
   return 0;
 }
 
-static int launch_fused(pmf_ctx *c, bool want_gx, bool want_gy) {
-  // variant: waves per workgroup NW and 32-row blocks per wave RBW (the workgroup's row panel is 32*NW*RBW rows)
-  //   K <= 32 : 8 waves x 2 row blocks (per-tile overheads amortised over twice the MFMA work; x 1 with batch layers)
-  //   K <= 64 : 8 waves x 1          K <= 128 : 4 waves x 1 (one wave per SIMD, whole register file)
-  // PMF_RBW=1 forces one row block for K <= 32 (development comparison; 4 waves x 2 blocks at K = 64 measured 3 % slower
-  // than 8 x 1 and was removed)
+// Variant and chunking of a fused data pass.
+//   variant: waves per workgroup NW and 32-row blocks per wave RBW (the workgroup's row panel is 32*NW*RBW rows)
+//     K <= 32 : 8 waves x 2 row blocks (per-tile overheads amortised over twice the MFMA work; x 1 with batch layers)
+//     K <= 64 : 8 waves x 1          K <= 128 : 4 waves x 1 (one wave per SIMD, whole register file)
+//   PMF_RBW=1 forces one row block for K <= 32 (development comparison; 4 waves x 2 blocks at K = 64 measured 3 % slower
+//   than 8 x 1 and was removed)
+//   chunks: the column tiles are walked in S contiguous chunks, one launch each.  S = 1 unless the context has a
+//   communicator with more than one rank (then the all-reduce of chunk s's grad(Y) runs beside the launches of the later
+//   chunks and of the next epoch's earlier ones, pmf_fit) or pmf_comm_set_chunks asked for it.
+static FusedGeom fused_geometry(pmf_ctx *c, bool want_gx, bool want_gy, bool allow_chunks) {
+  FusedGeom g;
   const char *rbwenv = getenv("PMF_RBW");
   // (the batch-layer epilogue of two row blocks does not fit the 256-register budget: RBW = 2 spills and is 1.5x slower)
-  const int NW = c->KB <= 2 ? 8 : 4;
-  int RBW = (c->KB == 1 && c->n_bv == 0) ? 2 : 1;
-  if (rbwenv && c->KB == 1 && atoi(rbwenv) == 1) RBW = 1;
-  // split-bf16 products (opt-in, pmf_set_precision): K <= 64, no batch layers; one row block per wave
+  g.NW = c->KB <= 2 ? 8 : 4;
+  g.RBW = (c->KB == 1 && c->n_bv == 0) ? 2 : 1;
+  if (rbwenv && c->KB == 1 && atoi(rbwenv) == 1) g.RBW = 1;
+  // split-bf16 products (opt-in, pmf_set_precision): K <= 64; one row block per wave
   // (batch layers: through the dense LDS table only, i.e. <= 15 batches per view, and as many views as LDS has room for)
   const bool sb_batch_ok = c->n_bv == 0 || (c->btd_ok && c->n_bv <= (c->KB == 1 ? SbCfg<1>::max_bv : SbCfg<2>::max_bv));
-  const bool sb = c->precision == PMF_PREC_BF16X3 && c->KB <= 2 && sb_batch_ok && (want_gx || want_gy) && !getenv("PMF_DEBUG_FLAGS");
-  if (sb) RBW = 1;
-  const int BM = 32 * NW * RBW;
-  const int64_t n_rp = (c->M + BM - 1) / BM;
-  const int64_t n_ct = (c->N + PMF_BN - 1) / PMF_BN;  // column tiles
-  // Column segments.  The work split is balanced to a tile whatever the segmentation, so the segment length only trades
-  //   (a) the fixed cost of a piece (X panel, first Y / D tile, gX flush: ~8 us) -- a workgroup walks
-  //       (T/G)/tps + 2 pieces -- against
-  //   (b) k_gy_reduce, which reads the private slabs of the ~G*tps/n_ct + 1 workgroups that visited a column tile
-  //       (Kp*N*4 bytes each at ~4 TB/s).
-  // tps* = sqrt(a/b) minimises a/tps + b*tps.
-  const int grid0 = (int)std::min<int64_t>(n_rp * n_ct, (int64_t)c->n_cu);
-  const double tiles_per_wg = (double)(n_rp * n_ct) / grid0;
+  g.sb = c->precision == PMF_PREC_BF16X3 && c->KB <= 2 && sb_batch_ok && (want_gx || want_gy) && !getenv("PMF_DEBUG_FLAGS");
+  if (g.sb) g.RBW = 1;
+  g.BM = 32 * g.NW * g.RBW;
+  g.n_rp = (c->M + g.BM - 1) / g.BM;
+  g.n_ct_all = (c->N + PMF_BN - 1) / PMF_BN;
+  g.grid_max = std::max(1, c->n_cu - (c->comm.nranks > 1 ? c->comm.reserve_cus : 0));
+  int S = 1;
+  if (allow_chunks && want_gy) {
+    S = c->n_chunks_req > 0 ? c->n_chunks_req : (c->comm.nranks > 1 ? 4 : 1);
+    // a chunk should give every workgroup a few dozen tiles at least (each launch pays its prologue and its tail)
+    const int64_t min_tiles = 32ll * g.grid_max;
+    while (S > 1 && (g.n_rp * g.n_ct_all) / S < min_tiles && c->n_chunks_req <= 0) --S;
+    S = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(S, PMF_MAX_CHUNKS), g.n_ct_all));
+  }
+  g.S = S;
+  for (int s = 0; s < S; ++s) {
+    g.ct0[s] = g.n_ct_all * s / S;
+    g.nct[s] = g.n_ct_all * (s + 1) / S - g.ct0[s];
+  }
+  return g;
+}
+
+// Column segmentation of one chunk.  The work split is balanced to a tile whatever the segmentation, so the segment
+// length only trades
+//   (a) the fixed cost of a piece (X panel, first Y / D tile, gX flush: ~8 us) -- a workgroup walks
+//       (T/G)/tps + 2 pieces -- against
+//   (b) k_gy_reduce, which reads the private slabs of the ~G*tps/n_ct + 1 workgroups that visited a column tile
+//       (Kp*N*4 bytes each at ~4 TB/s).
+// tps* = sqrt(a/b) minimises a/tps + b*tps.
+static void chunk_segments(pmf_ctx *c, const FusedGeom &g, int s, int &grid, int64_t &tps, int64_t &n_cseg) {
+  const int64_t n_ct = g.nct[s], n_rp = g.n_rp;
+  grid = (int)std::min<int64_t>(n_rp * n_ct, (int64_t)g.grid_max);
+  const double tiles_per_wg = (double)(n_rp * n_ct) / grid;
   const double a_cost = tiles_per_wg * 8e-6;
-  const double b_cost = (double)grid0 * (double)c->Kp * (double)c->N * 4.0 / ((double)n_ct * 4e12);
-  int64_t tiles_per_seg = (int64_t)std::llround(std::sqrt(a_cost / std::max(b_cost, 1e-12)));
+  const double b_cost = (double)grid * (double)c->Kp * (double)n_ct * 32.0 * 4.0 / ((double)n_ct * 4e12);
+  tps = (int64_t)std::llround(std::sqrt(a_cost / std::max(b_cost, 1e-12)));
   {
     const char *ts = getenv("PMF_TPS_SCALE");   // development: scale the model's segment length
-    if (ts) tiles_per_seg = (int64_t)std::llround((double)tiles_per_seg * atof(ts));
+    if (ts) tps = (int64_t)std::llround((double)tps * atof(ts));
   }
-  tiles_per_seg = std::max<int64_t>(std::min<int64_t>(8, n_ct), std::min<int64_t>(tiles_per_seg, n_ct));
+  tps = std::max<int64_t>(std::min<int64_t>(8, n_ct), std::min<int64_t>(tps, n_ct));
   // equal segments; the LAST one takes the remainder (it is longer, never tiny: every piece of work pays the fixed
   // prologue, so a 5-tile last segment once made one workgroup 20 % late)
-  const int64_t n_cseg = std::max<int64_t>(1, n_ct / tiles_per_seg);
-  const int64_t n_tiles = n_rp * n_ct;   // the kernel's work items, dealt out in contiguous, balanced ranges
-  const int grid = (int)std::min<int64_t>(n_tiles, (int64_t)c->n_cu);
-  if (grid > c->loss_cap) {
-    PMFCHK(dev_alloc(&c->loss_partial, (size_t)grid));
-    c->loss_cap = grid;
+  n_cseg = std::max<int64_t>(1, n_ct / tps);
+}
+
+// Everything a data pass needs before its first launch: work splits of all chunks (cached), the gX slot map, buffers.
+static int prepare_fused_pass(pmf_ctx *c, const FusedGeom &g, bool want_gx, bool want_gy) {
+  if ((int)c->splits.size() < g.S) c->splits.resize((size_t)g.S);
+  int64_t grid_sum = 0, serial_sum = 0;
+  for (int s = 0; s < g.S; ++s) {
+    int grid; int64_t tps, n_cseg;
+    chunk_segments(c, g, s, grid, tps, n_cseg);
+    PMFCHK(compute_work_split(c, c->splits[(size_t)s], grid, g.n_rp, g.ct0[s], g.nct[s], tps, n_cseg));
+    grid_sum += grid;
   }
-  c->n_macro = grid;                     // loss partials: one per workgroup
+  serial_sum = c->split_serial * PMF_MAX_CHUNKS + g.S;   // (split_serial is bumped by every recomputed split)
+  if (grid_sum > c->loss_cap) {
+    PMFCHK(dev_alloc(&c->loss_partial, (size_t)grid_sum));
+    c->loss_cap = grid_sum;
+  }
+  c->n_macro = grid_sum;                 // loss partials: one per workgroup and chunk
   const int64_t slab_stride = (int64_t)c->Kp * c->N;
-  if (want_gy && (size_t)grid * (size_t)slab_stride > c->gy_slabs_cap) {
+  if (want_gy && (size_t)g.grid_max * (size_t)slab_stride > c->gy_slabs_cap) {
     dev_free(&c->gy_slabs);
-    PMFCHK(dev_alloc(&c->gy_slabs, (size_t)grid * (size_t)slab_stride, false));   // never read before written
-    c->gy_slabs_cap = (size_t)grid * (size_t)slab_stride;
+    PMFCHK(dev_alloc(&c->gy_slabs, (size_t)g.grid_max * (size_t)slab_stride, false));   // never read before written
+    c->gy_slabs_cap = (size_t)g.grid_max * (size_t)slab_stride;
+  }
+  if (want_gx && serial_sum != c->gx_serial) {
+    // slot map of the gX partial slabs: chunk s owns slots [slot_base, slot_base + pieces); per row panel, its slots in
+    // work-sequence order (chunk, then segment, then position inside the unit) -- the order k_gx_reduce sums them in
+    std::vector<std::vector<int32_t>> lists((size_t)g.n_rp);
+    int32_t base = 0;
+    for (int s = 0; s < g.S; ++s) {
+      WorkSplit &ws = c->splits[(size_t)s];
+      ws.slot_base = base;
+      for (size_t p = 0; p < ws.piece_rp.size(); ++p) lists[(size_t)ws.piece_rp[p]].push_back(base + (int32_t)p);
+      std::vector<int32_t> abs(ws.h_piece_base);
+      for (auto &v : abs) v += base;
+      HIPCHK(hipMemcpy(ws.d_piece_base_abs, abs.data(), sizeof(int32_t) * abs.size(), hipMemcpyHostToDevice));
+      base += (int32_t)ws.piece_rp.size();
+    }
+    std::vector<int32_t> off((size_t)g.n_rp + 1, 0), idx;
+    for (int64_t rp = 0; rp < g.n_rp; ++rp) {
+      idx.insert(idx.end(), lists[(size_t)rp].begin(), lists[(size_t)rp].end());
+      off[(size_t)rp + 1] = (int32_t)idx.size();
+    }
+    if (idx.empty()) idx.push_back(0);
+    PMFCHK(dev_alloc(&c->gx_off, off.size(), false));
+    PMFCHK(dev_alloc(&c->gx_idx, idx.size(), false));
+    HIPCHK(hipMemcpy(c->gx_off, off.data(), sizeof(int32_t) * off.size(), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(c->gx_idx, idx.data(), sizeof(int32_t) * idx.size(), hipMemcpyHostToDevice));
+    const size_t need = (size_t)base * (size_t)g.BM * (size_t)c->Kp;
+    if (need > c->gx_part_cap) {
+      dev_free(&c->gx_part);
+      PMFCHK(dev_alloc(&c->gx_part, need, false));   // every slot is written whole by its piece before it is read
+      c->gx_part_cap = need;
+    }
+    c->gx_serial = serial_sum;
   }
   PMFCHK(ensure_tile_flags(c));
-  PMFCHK(compute_work_split(c, grid, n_rp, n_ct, tiles_per_seg, n_cseg));
+  if (g.sb) {
+    const size_t blk = c->KB == 1 ? SbCfg<1>::BLK : SbCfg<2>::BLK;
+    const size_t xb = (size_t)c->nRB * blk, yb = (size_t)g.n_ct_all * blk;
+    if (xb > c->xsb_cap) { dev_free(&c->xsb); c->xsb_cap = 0; PMFCHK(dev_alloc(&c->xsb, xb, false)); c->xsb_cap = xb; }
+    if (yb > c->ysb_cap) { dev_free(&c->ysb); c->ysb_cap = 0; PMFCHK(dev_alloc(&c->ysb, yb, false)); c->ysb_cap = yb; }
+  }
+  return 0;
+}
+
+// split-bf16 operand images (k_sb_split): X once per pass, sigma*Y per chunk (its columns only: the Y step of a later
+// chunk of the previous epoch may not have run yet when an earlier chunk is launched, pmf_fit)
+static int sb_split_x(pmf_ctx *c) {
+  SbSplitArgs sx = {c->P[0].p, nullptr, c->M, c->nRB, c->xsb};
+  if (c->KB == 1) k_sb_split<1><<<nblocks(c->nRB * 32 * 4, 256), 256, 0, c->stream>>>(sx);
+  else k_sb_split<2><<<nblocks(c->nRB * 32 * 8, 256), 256, 0, c->stream>>>(sx);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+static int sb_split_y(pmf_ctx *c, int64_t ct0, int64_t nct) {
+  const size_t blk = c->KB == 1 ? SbCfg<1>::BLK : SbCfg<2>::BLK;
+  const int64_t col0 = ct0 * 32;
+  SbSplitArgs sy = {c->P[1].p + col0 * c->Kp, c->colp + col0, c->N - col0, nct, c->ysb + (size_t)ct0 * blk};
+  if (c->KB == 1) k_sb_split<1><<<nblocks(nct * 32 * 4, 256), 256, 0, c->stream>>>(sy);
+  else k_sb_split<2><<<nblocks(nct * 32 * 8, 256), 256, 0, c->stream>>>(sy);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+// One chunk of the data pass: the fused kernel over column tiles [ct0, ct0 + nct) and the fixed-order reduction of its
+// private gY slabs; after the LAST chunk, the fixed-order reduction of the gX partial slabs.
+static int launch_fused_chunk(pmf_ctx *c, const FusedGeom &g, int s, bool want_gx, bool want_gy) {
+  WorkSplit &ws = c->splits[(size_t)s];
+  const int grid = ws.grid;
+  int grid_dummy; int64_t tiles_per_seg, n_cseg;
+  chunk_segments(c, g, s, grid_dummy, tiles_per_seg, n_cseg);
+  const int64_t n_ct = g.nct[s], n_rp = g.n_rp;
+  const int64_t slab_stride = (int64_t)c->Kp * c->N;
+  int64_t loss_off = 0;
+  for (int q = 0; q < s; ++q) loss_off += c->splits[(size_t)q].grid;
   FusedArgs a;
   memset(&a, 0, sizeof(a));
   a.tflags = c->tflags;
-  a.wg_begin = c->wg_begin;
+  a.wg_begin = ws.wg_begin;
   a.D = c->D; a.X = c->P[0].p; a.Y = c->P[1].p; a.gX = c->P[0].g; a.gY = c->P[1].g;
-  a.colp = c->colp; a.bor = c->bor; a.btab = c->btab; a.loss_partial = c->loss_partial;
+  a.colp = c->colp; a.bor = c->bor; a.btab = c->btab; a.loss_partial = c->loss_partial + loss_off;
   a.btd = (c->n_bv > 0 && c->btd_ok) ? c->btd : nullptr; a.n_bv = c->n_bv;
   a.nRB = c->nRB; a.gy_slabs = c->gy_slabs; a.slab_stride = slab_stride; a.n_rp = n_rp;
-  a.M = c->M; a.N = c->N; a.n_tiles = n_tiles; a.tps = (int)tiles_per_seg; a.n_ct = (int)n_ct; a.n_cseg = (int)n_cseg;
+  a.M = c->M; a.N = c->N; a.n_tiles = n_rp * n_ct; a.tps = (int)tiles_per_seg; a.n_ct = (int)n_ct; a.n_cseg = (int)n_cseg;
   a.want_gx = want_gx; a.want_gy = want_gy;
+  a.ct0 = (int32_t)g.ct0[s];
+  a.gx_part = c->gx_part; a.piece_base = ws.d_piece_base_abs; a.gx_slot_stride = (int64_t)g.BM * c->Kp;
   {
     const char *dbg = getenv("PMF_DEBUG_FLAGS");
     a.dbg = dbg ? atoi(dbg) : 0;
@@ -1568,21 +1800,9 @@ static int launch_fused(pmf_ctx *c, bool want_gx, bool want_gy) {
 #endif
   a.views = c->d_views;
   const bool batch = c->n_bv > 0;
-  if (sb) {
-    const size_t blk = c->KB == 1 ? SbCfg<1>::BLK : SbCfg<2>::BLK;
-    const size_t xb = (size_t)c->nRB * blk, yb = (size_t)n_ct * blk;
-    if (xb > c->xsb_cap) { dev_free(&c->xsb); c->xsb_cap = 0; PMFCHK(dev_alloc(&c->xsb, xb, false)); c->xsb_cap = xb; }
-    if (yb > c->ysb_cap) { dev_free(&c->ysb); c->ysb_cap = 0; PMFCHK(dev_alloc(&c->ysb, yb, false)); c->ysb_cap = yb; }
-    SbSplitArgs sx = {c->P[0].p, nullptr, c->M, c->nRB, c->xsb};
-    SbSplitArgs sy = {c->P[1].p, c->colp, c->N, n_ct, c->ysb};
-    if (c->KB == 1) {
-      k_sb_split<1><<<nblocks(c->nRB * 32 * 4, 256), 256, 0, c->stream>>>(sx);
-      k_sb_split<1><<<nblocks(n_ct * 32 * 4, 256), 256, 0, c->stream>>>(sy);
-    } else {
-      k_sb_split<2><<<nblocks(c->nRB * 32 * 8, 256), 256, 0, c->stream>>>(sx);
-      k_sb_split<2><<<nblocks(n_ct * 32 * 8, 256), 256, 0, c->stream>>>(sy);
-    }
-    HIPCHK(hipGetLastError());
+  if (g.sb) {
+    if (s == 0) PMFCHK(sb_split_x(c));
+    PMFCHK(sb_split_y(c, g.ct0[s], n_ct));
     a.Xsb = c->xsb; a.Ysb = c->ysb;
   }
   // timing events
@@ -1600,7 +1820,7 @@ static int launch_fused(pmf_ctx *c, bool want_gx, bool want_gy) {
   auto &ev = c->ev_pool[c->ev_used++];
   HIPCHK(hipEventRecord(ev.first, c->stream));
   int rc = 0;
-  if (sb) {
+  if (g.sb) {
     void (*kern)(const FusedArgs) = nullptr;
     // (the batch-layer variants exist with the per-tile noise-model dispatch only: MIXED = true also serves uniform models)
 #define PMF_SB_PICK_G(KBv, MX, BT) (want_gx && want_gy ? pmf_fused_sb_kernel<KBv, MX, true, true, BT>                                        \
@@ -1610,17 +1830,12 @@ static int launch_fused(pmf_ctx *c, bool want_gx, bool want_gy) {
 #undef PMF_SB_PICK
 #undef PMF_SB_PICK_G
     const size_t lds = (c->KB == 1 ? SbCfg<1>::lds_bytes : SbCfg<2>::lds_bytes) + (batch ? SbCfg<1>::lds_batch(c->n_bv) : 0);
-    static size_t sb_attr[32] = {};   // largest dynamic LDS size set so far, per variant
-    const int vi = (batch ? 16 : 0) + (c->KB == 1 ? 8 : 0) + (want_gy ? 4 : 0) + (want_gx ? 2 : 0) + (c->mixed ? 1 : 0);
-    if (sb_attr[vi] < lds) {
-      HIPCHK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      sb_attr[vi] = lds;
-    }
+    PMFCHK(ensure_dyn_lds(c, (const void *)kern, lds));
     hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, c->stream, a);
     HIPCHK(hipGetLastError());
     c->sb_launches += 1;
   } else
-  switch (c->KB * 10 + RBW) {
+  switch (c->KB * 10 + g.RBW) {
     case 11: rc = launch_fused_t<1, 8, 1>(c, a, grid, batch, c->mixed); break;
     case 12: rc = launch_fused_t<1, 8, 2>(c, a, grid, batch, c->mixed); break;
     case 21: rc = launch_fused_t<2, 8, 1>(c, a, grid, batch, c->mixed); break;
@@ -1631,10 +1846,24 @@ static int launch_fused(pmf_ctx *c, bool want_gx, bool want_gy) {
   PMFCHK(rc);
   HIPCHK(hipEventRecord(ev.second, c->stream));   // the events bracket pmf_fused_kernel alone (= rocprofv3's kernel duration)
   if (want_gy && !(a.dbg & 8)) {
-    k_gy_reduce<<<dim3((unsigned)a.n_ct, (unsigned)(32 * c->Kp / 256)), 64, 0, c->stream>>>(c->gy_slabs, slab_stride, c->c_off, c->c_idx,
-                                                                                        c->Kp, c->N, c->P[1].g);
+    k_gy_reduce<<<dim3((unsigned)n_ct, (unsigned)(32 * c->Kp / 256)), 64, 0, c->stream>>>(c->gy_slabs, slab_stride, ws.c_off, ws.c_idx,
+                                                                                      c->Kp, c->N, c->P[1].g, (int)g.ct0[s]);
     HIPCHK(hipGetLastError());
   }
+  if (want_gx && s == g.S - 1) {
+    const int64_t panel = (int64_t)g.BM * c->Kp;
+    k_gx_reduce<<<dim3((unsigned)g.n_rp, (unsigned)((panel / 4 + 255) / 256)), 256, 0, c->stream>>>(
+        c->gx_part, panel, c->gx_off, c->gx_idx, panel, (int64_t)c->Kp * c->M, c->P[0].g);
+    HIPCHK(hipGetLastError());
+  }
+  return 0;
+}
+
+// the whole data pass in one go (step-level API, single-chunk callers)
+static int launch_fused(pmf_ctx *c, bool want_gx, bool want_gy) {
+  const FusedGeom g = fused_geometry(c, want_gx, want_gy, /*allow_chunks=*/c->n_chunks_req > 0);   // (chunks only on request)
+  PMFCHK(prepare_fused_pass(c, g, want_gx, want_gy));
+  for (int s = 0; s < g.S; ++s) PMFCHK(launch_fused_chunk(c, g, s, want_gx, want_gy));
   return 0;
 }
 
@@ -1680,7 +1909,7 @@ static int launch_layer_grad(pmf_ctx *c, const pmf_fit_opts *o, bool with_loss) 
     case 4: kern = k_layer_grad<4>; break;
     default: return pmf_fail("unsupported KB=%d", c->KB);
   }
-  HIPCHK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  PMFCHK(ensure_dyn_lds(c, (const void *)kern, lds));
   hipLaunchKernelGGL(kern, dim3(gx, (unsigned)gy), dim3(64), lds, c->stream, a);
   HIPCHK(hipGetLastError());
   return 0;
@@ -1728,7 +1957,7 @@ static int launch_layer_pass(pmf_ctx *c, const pmf_fit_opts *o, bool with_loss) 
     case 3: kern = c->mixed ? pmf_layer_kernel<3, 4, true> : pmf_layer_kernel<3, 4, false>; lds = LayerCfg<3, 4>::lds_bytes; break;
     default: kern = c->mixed ? pmf_layer_kernel<4, 4, true> : pmf_layer_kernel<4, 4, false>; lds = LayerCfg<4, 4>::lds_bytes; break;
   }
-  HIPCHK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  PMFCHK(ensure_dyn_lds(c, (const void *)kern, lds));
   hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * lnw), lds, c->stream, a);
   HIPCHK(hipGetLastError());
   LayerMapArgs m;
@@ -1753,49 +1982,76 @@ static int check_ready(pmf_ctx *c) {
   return 0;
 }
 
-static int step_param(pmf_ctx *c, int which, bool do_step, bool use_reg, int reg_slot, int *reg_count) {
+// Regularizer + optimizer step of elements [e0, e0 + n) of parameter `which` (whole tensor: e0 = 0, n = b.n).  For X / Y,
+// e0 and n are multiples of Kp (whole columns): the pipelined loop of pmf_fit steps Y one column chunk at a time.
+// `max_blocks` bounds the grid (= loss partials appended to the slab); `advance` moves Adam's running beta powers on
+// (once per epoch, with the last slice).
+static int step_param_range(pmf_ctx *c, int which, int64_t e0, int64_t n, bool do_step, bool use_reg, int reg_slot,
+                            int *reg_count, int max_blocks, bool advance) {
   ParamBuf &b = c->P[which];
-  if (b.n == 0) return 0;
+  if (b.n == 0 || n == 0) return 0;
   StepArgs s;
   memset(&s, 0, sizeof(s));
-  s.p = b.p; s.g = b.g; s.acc = b.acc; s.mom = b.mom; s.wq = b.wq; s.cq = b.cq;
-  if (which == 1 && c->has_ard) { s.ard_alpha = c->ard_alpha; s.ard_beta = c->ard_beta; s.ard_scale = c->ard_scale; }
-  s.n = b.n;
+  s.p = b.p + e0; s.g = b.g + e0; s.acc = b.acc + e0; s.mom = b.mom + e0;
+  s.wq = b.wq ? b.wq + e0 : nullptr; s.cq = b.cq ? b.cq + e0 : nullptr;
   s.Kp = which <= 1 ? c->Kp : 1;
   s.K = which <= 1 ? c->K : 1;
+  if (which == 1 && c->has_ard) { s.ard_alpha = c->ard_alpha + e0 / s.Kp; s.ard_beta = c->ard_beta + e0; s.ard_scale = c->ard_scale; }
+  s.n = n;
   s.opt_kind = c->opt_kind; s.lr = c->lr; s.eps = c->eps; s.b1 = c->b1; s.b2 = c->b2;
   s.c1 = 1.f - b.bp1; s.c2 = 1.f - b.bp2;
   s.do_step = do_step; s.use_reg = use_reg;
-  // the four layer parameters share one slab of loss partials: each gets a quarter (k_reg_step is grid-stride)
-  const int grid = (int)std::min<int64_t>(reg_slot == 2 ? REG_SLOTS / 4 : REG_SLOTS, nblocks(b.n, 256));
+  const int grid = (int)std::min<int64_t>(max_blocks, nblocks(n, 256));
   s.reg_partial = c->reg_partial + (int64_t)reg_slot * REG_SLOTS + *reg_count;
   if (*reg_count + grid > REG_SLOTS) return pmf_fail("internal: regularizer partial slab overflow");
   k_reg_step<<<grid, 256, 0, c->stream>>>(s);
   HIPCHK(hipGetLastError());
   *reg_count += grid;
-  if (do_step && c->opt_kind == PMF_OPT_ADAM) { b.bp1 *= c->b1; b.bp2 *= c->b2; }
+  if (advance && do_step && c->opt_kind == PMF_OPT_ADAM) { b.bp1 *= c->b1; b.bp2 *= c->b2; }
   return 0;
+}
+static int step_param(pmf_ctx *c, int which, bool do_step, bool use_reg, int reg_slot, int *reg_count) {
+  // the four layer parameters share one slab of loss partials: each gets a quarter (k_reg_step is grid-stride)
+  return step_param_range(c, which, 0, c->P[which].n, do_step, use_reg, reg_slot, reg_count, reg_slot == 2 ? REG_SLOTS / 4 : REG_SLOTS, true);
+}
+// layer l <-> param: 1 logsigma(2), 2 logdelta(4), 3 mu(3), 4 theta(5)
+static int step_layers(pmf_ctx *c, const pmf_fit_opts *o, int *reg_count) {
+  const int fl = o->frozen_layers, fr = o->frozen_regs;
+  const int pmap[4] = {2, 4, 3, 5};
+  for (int l = 0; l < 4; ++l) {
+    const bool frozen = (fl >> l) & 1;
+    const bool reg_on = !frozen && !((fr >> l) & 1);
+    if (frozen) continue;  // FrozenLayer: no step, regularizer evaluates to 0 (regularizers.jl:508-510, 887-889)
+    PMFCHK(step_param(c, pmap[l], true, reg_on, 2, reg_count));
+  }
+  c->prepared = false;
+  return 0;
+}
+
+// what every epoch starts with: optimizer state, prepared column / batch tables, cleared layer gradients
+static int epoch_open(pmf_ctx *c, const pmf_fit_opts *o) {
+  if (!c->state_init) PMFCHK(init_opt_state(c));
+  if (!c->prepared || o->update_col_layers) PMFCHK(prepare(c));
+  // (grad(X) and grad(Y) need no clearing: k_gx_reduce / k_gy_reduce overwrite every element)
+  if (o->update_col_layers)
+    for (int w = 2; w < 6; ++w)
+      if (c->P[w].n) HIPCHK(hipMemsetAsync(c->P[w].g, 0, sizeof(float) * (size_t)c->P[w].n, c->stream));
+  return 0;
+}
+static int epoch_layer_pass(pmf_ctx *c, const pmf_fit_opts *o, bool with_loss) {
+  if (layer_pass_eligible(c)) return launch_layer_pass(c, o, with_loss);
+  return launch_layer_grad(c, o, with_loss);
 }
 
 extern "C" int pmf_epoch_begin(pmf_ctx *c, const pmf_fit_opts *o) {
   PMFCHK(ctx_bind(c));
   PMFCHK(check_ready(c));
   if (!o) return pmf_fail("null opts");
-  if (!c->state_init) PMFCHK(init_opt_state(c));
-  if (!c->prepared || o->update_col_layers) PMFCHK(prepare(c));
+  PMFCHK(epoch_open(c, o));
   for (int q = 0; q < 4; ++q) c->reg_counts[q] = 0;
   const bool fused = o->update_X || o->update_Y || !o->update_col_layers;
-  // gradients are accumulated with atomics: start every epoch from zero
-  if (o->update_X) HIPCHK(hipMemsetAsync(c->P[0].g, 0, sizeof(float) * (size_t)c->P[0].n, c->stream));
-  // (grad(Y) needs no clearing: k_gy_reduce overwrites every element)
-  if (o->update_col_layers)
-    for (int w = 2; w < 6; ++w)
-      if (c->P[w].n) HIPCHK(hipMemsetAsync(c->P[w].g, 0, sizeof(float) * (size_t)c->P[w].n, c->stream));
   if (fused) PMFCHK(launch_fused(c, o->update_X != 0, o->update_Y != 0));
-  if (o->update_col_layers) {
-    if (layer_pass_eligible(c)) PMFCHK(launch_layer_pass(c, o, !fused));
-    else PMFCHK(launch_layer_grad(c, o, !fused));
-  }
+  if (o->update_col_layers) PMFCHK(epoch_layer_pass(c, o, !fused));
   return 0;
 }
 
@@ -1808,18 +2064,7 @@ extern "C" int pmf_epoch_step_local(pmf_ctx *c, const pmf_fit_opts *o) {
 extern "C" int pmf_epoch_step_shared(pmf_ctx *c, const pmf_fit_opts *o) {
   PMFCHK(ctx_bind(c));
   if (o->update_Y) PMFCHK(step_param(c, 1, true, true, 1, &c->reg_counts[1]));
-  if (o->update_col_layers) {
-    const int fl = o->frozen_layers, fr = o->frozen_regs;
-    // layer l <-> param: 1 logsigma(2), 2 logdelta(4), 3 mu(3), 4 theta(5)
-    const int pmap[4] = {2, 4, 3, 5};
-    for (int l = 0; l < 4; ++l) {
-      const bool frozen = (fl >> l) & 1;
-      const bool reg_on = !frozen && !((fr >> l) & 1);
-      if (frozen) continue;  // FrozenLayer: no step, regularizer evaluates to 0 (regularizers.jl:508-510, 887-889)
-      PMFCHK(step_param(c, pmap[l], true, reg_on, 2, &c->reg_counts[2]));
-    }
-    c->prepared = false;
-  }
+  if (o->update_col_layers) PMFCHK(step_layers(c, o, &c->reg_counts[2]));
   return 0;
 }
 
@@ -1827,7 +2072,7 @@ extern "C" int pmf_epoch_loss(pmf_ctx *c, double *local_loss, double *shared_ter
   PMFCHK(ctx_bind(c));
   RegCounts rc;
   for (int q = 0; q < 4; ++q) rc.c[q] = c->reg_counts[q];
-  k_loss_reduce<<<1, 256, 0, c->stream>>>(c->loss_partial, c->n_macro, c->reg_partial, rc, c->d_loss);
+  k_loss_reduce<<<1, 256, 0, c->stream>>>(c->loss_partial, c->n_macro, c->reg_partial, rc, c->d_loss, 0x1f);
   HIPCHK(hipGetLastError());
   HIPCHK(hipMemcpyAsync(c->h_loss, c->d_loss, sizeof(double) * 5, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));
@@ -1838,19 +2083,370 @@ extern "C" int pmf_epoch_loss(pmf_ctx *c, double *local_loss, double *shared_ter
   return 0;
 }
 
+// ------------------------------------------------------------------------------------------------
+// cross-rank exchange (no reference counterpart: the reference is single-GPU, one process per GPU being its
+// habit for independent fits, analyses/scripts/julia/script_util.jl:278-306)
+// ------------------------------------------------------------------------------------------------
+struct RcclApi {
+  void *dl = nullptr;
+  ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+  ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*GroupStart)() = nullptr;
+  ncclResult_t (*GroupEnd)() = nullptr;
+  const char *(*GetErrorString)(ncclResult_t) = nullptr;
+  const char *(*GetLastError)(ncclComm_t) = nullptr;
+};
+static RcclApi g_rccl;
+// RCCL is loaded on first use (dlopen): a single-GPU host never maps the 570 MB library, and libpmf_hip.so has no
+// link-time dependency on it.  librccl.so.1 resolves to the ROCm installation the library's own HIP runtime comes from.
+static int rccl_load() {
+  if (g_rccl.dl) return 0;
+  // The RCCL that belongs to THIS library's HIP runtime: the librccl.so.1 next to the libamdhip64 our HIP calls are bound
+  // to.  (A process that also holds PyTorch-ROCm has a second HIP runtime and a second RCCL, torch's bundled ones; a
+  // stream of one runtime must not reach the other's RCCL.)  PMF_RCCL_LIB overrides; plain names are the fallback.
+  std::string sibling;
+  {
+    Dl_info info;
+    if (dladdr((void *)&hipStreamCreateWithFlags, &info) && info.dli_fname) {
+      std::string p(info.dli_fname);
+      const size_t k = p.rfind('/');
+      if (k != std::string::npos) sibling = p.substr(0, k + 1) + "librccl.so.1";
+    }
+  }
+  const char *names[] = {getenv("PMF_RCCL_LIB"), sibling.empty() ? nullptr : sibling.c_str(), "librccl.so.1", "librccl.so"};
+  void *dl = nullptr;
+  for (const char *nm : names) {
+    if (!nm || !*nm) continue;
+    dl = dlopen(nm, RTLD_NOW | RTLD_LOCAL);
+    if (dl) break;
+  }
+  if (!dl) return pmf_fail("cannot load librccl.so.1 (%s): multi-GPU fits need RCCL", dlerror());
+  RcclApi r;
+  r.dl = dl;
+#define PMF_SYM(field, name)                                                          \
+  *(void **)(&r.field) = dlsym(dl, name);                                             \
+  if (!r.field) return pmf_fail("librccl: symbol %s not found", name)
+  PMF_SYM(GetUniqueId, "ncclGetUniqueId");
+  PMF_SYM(CommInitRank, "ncclCommInitRank");
+  PMF_SYM(CommDestroy, "ncclCommDestroy");
+  PMF_SYM(AllReduce, "ncclAllReduce");
+  PMF_SYM(GroupStart, "ncclGroupStart");
+  PMF_SYM(GroupEnd, "ncclGroupEnd");
+  PMF_SYM(GetErrorString, "ncclGetErrorString");
+#undef PMF_SYM
+  *(void **)(&r.GetLastError) = dlsym(dl, "ncclGetLastError");
+  g_rccl = r;
+  return 0;
+}
+static int rccl_chk(ncclResult_t rc, const char *what, ncclComm_t comm = nullptr) {
+  if (rc == ncclSuccess) return 0;
+  const char *detail = (g_rccl.GetLastError && comm) ? g_rccl.GetLastError(comm) : "";
+  return pmf_fail("%s failed: %s %s", what, g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "?", detail ? detail : "");
+}
+
+extern "C" int pmf_comm_get_unique_id(void *id_out) {
+  if (!id_out) return pmf_fail("null id buffer");
+  PMFCHK(rccl_load());
+  ncclUniqueId id;
+  PMFCHK(rccl_chk(g_rccl.GetUniqueId(&id), "ncclGetUniqueId"));
+  static_assert(sizeof(ncclUniqueId) == PMF_COMM_ID_BYTES, "ncclUniqueId size");
+  memcpy(id_out, &id, sizeof(id));
+  return 0;
+}
+
+static bool comm_active(const pmf_ctx *c) { return c->comm.nccl != nullptr || c->comm.host_fn != nullptr; }
+
+static int comm_release(pmf_ctx *c) {
+  Comm &m = c->comm;
+  if (m.stream) (void)hipStreamSynchronize(m.stream);
+  if (m.nccl && g_rccl.CommDestroy) (void)g_rccl.CommDestroy((ncclComm_t)m.nccl);
+  m.nccl = nullptr;
+  m.host_fn = nullptr;
+  m.host_user = nullptr;
+  for (auto e : m.ev_ready) (void)hipEventDestroy(e);
+  for (auto e : m.ev_done) (void)hipEventDestroy(e);
+  m.ev_ready.clear(); m.ev_done.clear();
+  hipEvent_t *evs[4] = {&m.ev_loss_ready, &m.ev_loss_done, &m.ev_layer_ready, &m.ev_layer_done};
+  for (auto pe : evs) { if (*pe) (void)hipEventDestroy(*pe); *pe = nullptr; }
+  if (m.stream) (void)hipStreamDestroy(m.stream);
+  m.stream = nullptr;
+  if (m.stage) (void)hipHostFree(m.stage);
+  m.stage = nullptr; m.stage_bytes = 0;
+  m.rank = 0; m.nranks = 1; m.reserve_cus = 0;
+  return 0;
+}
+static int comm_common_init(pmf_ctx *c, int rank, int nranks) {
+  if (nranks < 1 || rank < 0 || rank >= nranks) return pmf_fail("bad rank %d of %d", rank, nranks);
+  comm_release(c);
+  Comm &m = c->comm;
+  m.rank = rank; m.nranks = nranks;
+  HIPCHK(hipStreamCreateWithFlags(&m.stream, hipStreamNonBlocking));
+  hipEvent_t *evs[4] = {&m.ev_loss_ready, &m.ev_loss_done, &m.ev_layer_ready, &m.ev_layer_done};
+  for (auto pe : evs) HIPCHK(hipEventCreateWithFlags(pe, hipEventDisableTiming));
+  return 0;
+}
+
+extern "C" int pmf_comm_init(pmf_ctx *c, int rank, int nranks, const void *unique_id) {
+  PMFCHK(ctx_bind(c));
+  if (!unique_id) return pmf_fail("null unique id");
+  PMFCHK(rccl_load());
+  // The fused pass is a persistent grid that fills every CU: a collective's kernels get a CU only when a workgroup
+  // retires.  With more than one rank the pass therefore leaves PMF_COMM_CTAS CUs (default 4) free and RCCL is held to
+  // as many channels (one workgroup each); 0 = no reservation, RCCL's own channel count.
+  int ctas = 4;
+  if (const char *e = getenv("PMF_COMM_CTAS")) ctas = atoi(e);
+  if (nranks > 1 && ctas > 0) {
+    char buf[16];
+    snprintf(buf, sizeof(buf), "%d", ctas);
+    setenv("NCCL_MAX_NCHANNELS", buf, 0);   // (not overwritten when the host has set it)
+  }
+  PMFCHK(comm_common_init(c, rank, nranks));
+  ncclUniqueId id;
+  memcpy(&id, unique_id, sizeof(id));
+  ncclComm_t comm = nullptr;
+  const int rc = rccl_chk(g_rccl.CommInitRank(&comm, nranks, id, rank), "ncclCommInitRank");
+  if (rc < 0) { comm_release(c); return rc; }
+  c->comm.nccl = comm;
+  c->comm.reserve_cus = nranks > 1 ? std::max(0, std::min(ctas, c->n_cu / 4)) : 0;
+  return 0;
+}
+
+extern "C" int pmf_comm_init_host(pmf_ctx *c, int rank, int nranks, pmf_host_allreduce_fn fn, void *user) {
+  PMFCHK(ctx_bind(c));
+  if (!fn) return pmf_fail("null all-reduce callback");
+  PMFCHK(comm_common_init(c, rank, nranks));
+  c->comm.host_fn = fn;
+  c->comm.host_user = user;
+  return 0;
+}
+
+extern "C" int pmf_comm_destroy(pmf_ctx *c) {
+  PMFCHK(ctx_bind(c));
+  return comm_release(c);
+}
+
+extern "C" int pmf_comm_set_chunks(pmf_ctx *c, int n_chunks) {
+  if (!c) return pmf_fail("null context");
+  if (n_chunks < 0 || n_chunks > PMF_MAX_CHUNKS) return pmf_fail("n_chunks=%d out of range (0..%d)", n_chunks, PMF_MAX_CHUNKS);
+  c->n_chunks_req = n_chunks;
+  return 0;
+}
+
+extern "C" int pmf_comm_info(pmf_ctx *c, int *rank, int *nranks, int *transport, int *n_chunks, int *reserved_cus,
+                             int64_t *n_collectives) {
+  if (!c) return pmf_fail("null context");
+  if (rank) *rank = c->comm.rank;
+  if (nranks) *nranks = c->comm.nranks;
+  if (transport) *transport = c->comm.nccl ? PMF_COMM_RCCL : (c->comm.host_fn ? PMF_COMM_HOST : PMF_COMM_NONE);
+  if (n_chunks) *n_chunks = c->last_chunks;
+  if (reserved_cus) *reserved_cus = c->comm.nranks > 1 ? c->comm.reserve_cus : 0;
+  if (n_collectives) *n_collectives = c->comm.n_allreduce;
+  return 0;
+}
+
+// in-place sum over the ranks of `count` elements at device address p, ordered on the communication stream
+static int comm_allreduce(pmf_ctx *c, void *p, int64_t count, bool f64) {
+  Comm &m = c->comm;
+  if (count <= 0) return 0;
+  m.n_allreduce++;
+  if (m.nccl)
+    return rccl_chk(g_rccl.AllReduce(p, p, (size_t)count, f64 ? ncclFloat64 : ncclFloat32, ncclSum, (ncclComm_t)m.nccl, m.stream),
+                    "ncclAllReduce", (ncclComm_t)m.nccl);
+  // host-staged transport (tests): device -> pinned host -> callback (e.g. gloo) -> device, blocking
+  const size_t bytes = (size_t)count * (f64 ? 8 : 4);
+  if (bytes > m.stage_bytes) {
+    if (m.stage) (void)hipHostFree(m.stage);
+    m.stage = nullptr; m.stage_bytes = 0;
+    HIPCHK(hipHostMalloc(&m.stage, bytes));
+    m.stage_bytes = bytes;
+  }
+  HIPCHK(hipMemcpyAsync(m.stage, p, bytes, hipMemcpyDeviceToHost, m.stream));
+  HIPCHK(hipStreamSynchronize(m.stream));
+  if (m.host_fn(m.host_user, m.stage, count, f64 ? 1 : 0) != 0) return pmf_fail("host all-reduce callback failed");
+  HIPCHK(hipMemcpyAsync(p, m.stage, bytes, hipMemcpyHostToDevice, m.stream));
+  HIPCHK(hipStreamSynchronize(m.stream));
+  return 0;
+}
+// Sum (op 0) or maximum (op 1) over the ranks of a HOST buffer through the communicator, for what the host keeps
+// between the GD stages: the column / batch statistics of pmf_stats, timings, flags.  Blocking.
+extern "C" int pmf_comm_allreduce(pmf_ctx *c, void *host_buf, int64_t count, int dtype, int op) {
+  PMFCHK(ctx_bind(c));
+  if (!host_buf || count < 0) return pmf_fail("bad buffer");
+  if (dtype != 0 && dtype != 1) return pmf_fail("dtype must be 0 (float32) or 1 (float64)");
+  if (op != 0 && op != 1) return pmf_fail("op must be 0 (sum) or 1 (max)");
+  if (!comm_active(c) || count == 0) return 0;   // one rank: nothing to do
+  Comm &m = c->comm;
+  const size_t bytes = (size_t)count * (dtype ? 8 : 4);
+  if (m.nccl) {
+    void *d = nullptr;
+    HIPCHK(hipMalloc(&d, bytes));
+    hipError_t e = hipMemcpyAsync(d, host_buf, bytes, hipMemcpyHostToDevice, m.stream);
+    int rc = 0;
+    if (e == hipSuccess)
+      rc = rccl_chk(g_rccl.AllReduce(d, d, (size_t)count, dtype ? ncclFloat64 : ncclFloat32, op ? ncclMax : ncclSum, (ncclComm_t)m.nccl, m.stream),
+                    "ncclAllReduce", (ncclComm_t)m.nccl);
+    if (e == hipSuccess && rc == 0) e = hipMemcpyAsync(host_buf, d, bytes, hipMemcpyDeviceToHost, m.stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(m.stream);
+    (void)hipFree(d);
+    if (rc < 0) return rc;
+    if (e != hipSuccess) return pmf_fail("pmf_comm_allreduce: %s", hipGetErrorString(e));
+    m.n_allreduce++;
+    return 0;
+  }
+  if (op != 0) return pmf_fail("the host-staged transport only sums");
+  if (m.host_fn(m.host_user, host_buf, count, dtype) != 0) return pmf_fail("host all-reduce callback failed");
+  m.n_allreduce++;
+  return 0;
+}
+
+// the communication stream continues after everything enqueued on the compute stream so far / vice versa
+static int comm_after_compute(pmf_ctx *c, hipEvent_t ev) {
+  HIPCHK(hipEventRecord(ev, c->stream));
+  HIPCHK(hipStreamWaitEvent(c->comm.stream, ev, 0));
+  return 0;
+}
+static int comm_mark(pmf_ctx *c, hipEvent_t ev) {
+  HIPCHK(hipEventRecord(ev, c->comm.stream));
+  return 0;
+}
+static int compute_after_comm(pmf_ctx *c, hipEvent_t ev) {
+  HIPCHK(hipStreamWaitEvent(c->stream, ev, 0));
+  return 0;
+}
+
+// MF.fit!(model.matfac, model.data; ...) (src/fit.jl:24-36): the epoch loop.
+//
+// One epoch = data pass (fused kernel over S column chunks [+ layer pass]) -> X step -> Y step per chunk [-> layer steps]
+// -> loss.  The loop is software-pipelined across epochs: the data pass of epoch e+1 is launched BEFORE the host has
+// seen the loss of epoch e -- chunk s of epoch e+1 right after the Y step of chunk s of epoch e, which is all it depends
+// on besides the X step -- so that
+//   * the host's wait for the loss (and its termination test) runs beside the next data pass instead of idling the GPU,
+//   * with a communicator, the all-reduce of chunk s's grad(Y) has until the Y step of chunk s to finish, i.e. it runs
+//     beside the launches of chunks s+1 .. S-1 of this epoch and 0 .. s-1 of the next: no collective sits on the
+//     critical path (one exchange step per epoch: S grad(Y) slices, the local loss as two doubles, and the layer
+//     gradients when they train).
+// A data pass only writes gradient buffers, never parameters: when epoch e terminates the fit, the speculative pass of
+// e+1 is simply dropped and the parameters are exactly those after epoch e's steps (same results as the plain loop).
 extern "C" int pmf_fit(pmf_ctx *c, const pmf_fit_opts *o, pmf_fit_result *res) {
   PMFCHK(ctx_bind(c));
   PMFCHK(check_ready(c));
   if (!o || !res) return pmf_fail("null opts/result");
   const auto t0 = std::chrono::steady_clock::now();
+  const bool ux = o->update_X != 0, uy = o->update_Y != 0, ul = o->update_col_layers != 0;
+  const bool fused = ux || uy || !ul;
+  const bool cm = comm_active(c);
+  FusedGeom g;
+  if (fused) g = fused_geometry(c, ux, uy, /*allow_chunks=*/!ul);
+  const int S = fused ? g.S : 1;
+  c->last_chunks = S;
+  Comm &m = c->comm;
+  if (cm) {
+    while ((int)m.ev_ready.size() < S) {
+      hipEvent_t e0, e1;
+      HIPCHK(hipEventCreateWithFlags(&e0, hipEventDisableTiming));
+      HIPCHK(hipEventCreateWithFlags(&e1, hipEventDisableTiming));
+      m.ev_ready.push_back(e0);
+      m.ev_done.push_back(e1);
+    }
+  }
+  if (!c->ev_host) HIPCHK(hipEventCreateWithFlags(&c->ev_host, hipEventDisableTiming));
   int term = PMF_TERM_MAX_EPOCHS, tol_iters = 0, n = 0, last_epoch = o->epoch - 1;
   double prev = 0.0, loss = 0.0;
   const int tol_max = o->tol_max_iters > 0 ? o->tol_max_iters : 3;
+
+  // chunk s of an epoch's data pass, with the exchange of what it completes
+  auto pass_chunk = [&](int s) -> int {
+    if (fused) {
+      PMFCHK(launch_fused_chunk(c, g, s, ux, uy));
+      if (cm && uy) {
+        const int64_t col0 = g.ct0[s] * 32, col1 = std::min<int64_t>(c->N, (g.ct0[s] + g.nct[s]) * 32);
+        PMFCHK(comm_after_compute(c, m.ev_ready[(size_t)s]));
+        PMFCHK(comm_allreduce(c, c->P[1].g + col0 * c->Kp, (col1 - col0) * c->Kp, false));
+        PMFCHK(comm_mark(c, m.ev_done[(size_t)s]));
+      }
+    }
+    if (ul && s == S - 1) {
+      PMFCHK(epoch_layer_pass(c, o, !fused));
+      if (cm) {
+        PMFCHK(comm_after_compute(c, m.ev_layer_ready));
+        if (m.nccl) PMFCHK(rccl_chk(g_rccl.GroupStart(), "ncclGroupStart"));
+        for (int w = 2; w < 6; ++w) PMFCHK(comm_allreduce(c, c->P[w].g, c->P[w].n, false));
+        if (m.nccl) PMFCHK(rccl_chk(g_rccl.GroupEnd(), "ncclGroupEnd", (ncclComm_t)m.nccl));
+        PMFCHK(comm_mark(c, m.ev_layer_done));
+      }
+    }
+    return 0;
+  };
+
+  bool in_flight = false;   // a data pass whose epoch has not been finished is enqueued
+  if (o->epoch <= o->max_epochs) {
+    PMFCHK(epoch_open(c, o));
+    if (fused) PMFCHK(prepare_fused_pass(c, g, ux, uy));
+    for (int s = 0; s < S; ++s) PMFCHK(pass_chunk(s));
+    in_flight = true;
+  }
   for (int epoch = o->epoch; epoch <= o->max_epochs; ++epoch) {
-    PMFCHK(pmf_epoch_begin(c, o));
-    PMFCHK(pmf_epoch_step_local(c, o));
-    PMFCHK(pmf_epoch_step_shared(c, o));
-    PMFCHK(pmf_epoch_loss(c, &loss, nullptr));
+    const bool more = epoch < o->max_epochs;
+    RegCounts rc;
+    for (int q = 0; q < 4; ++q) rc.c[q] = 0;
+    // ---- X step (row-local) and the rank-local part of the loss: data term + X regularizer
+    if (ux) PMFCHK(step_param(c, 0, true, true, 0, &rc.c[0]));
+    k_loss_reduce<<<1, 256, 0, c->stream>>>(c->loss_partial, c->n_macro, c->reg_partial, rc, c->d_loss, 0x03);
+    HIPCHK(hipGetLastError());
+    if (cm) {
+      PMFCHK(comm_after_compute(c, m.ev_loss_ready));
+      PMFCHK(comm_allreduce(c, c->d_loss, 2, true));
+      PMFCHK(comm_mark(c, m.ev_loss_done));
+    }
+    in_flight = false;
+    // ---- replicated parameters, chunk by chunk; the next epoch's chunk follows its Y step
+    for (int s = 0; s < S; ++s) {
+      if (uy) {
+        if (cm) PMFCHK(compute_after_comm(c, m.ev_done[(size_t)s]));
+        const int64_t col0 = fused ? g.ct0[s] * 32 : 0;
+        const int64_t col1 = fused ? std::min<int64_t>(c->N, (g.ct0[s] + g.nct[s]) * 32) : c->N;
+        PMFCHK(step_param_range(c, 1, col0 * c->Kp, (col1 - col0) * c->Kp, true, true, 1, &rc.c[1], REG_SLOTS / S, s == S - 1));
+      }
+      if (s == S - 1) {
+        if (ul) {
+          if (cm) PMFCHK(compute_after_comm(c, m.ev_layer_done));
+          PMFCHK(step_layers(c, o, &rc.c[2]));
+        }
+        if (cm) PMFCHK(compute_after_comm(c, m.ev_loss_done));
+        k_loss_reduce<<<1, 256, 0, c->stream>>>(c->loss_partial, c->n_macro, c->reg_partial, rc, c->d_loss, 0x1c);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(c->h_loss, c->d_loss, sizeof(double) * 5, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipEventRecord(c->ev_host, c->stream));
+      }
+      if (more) {
+        if (s == 0 && S > 1) PMFCHK(epoch_open(c, o));
+        if (s == S - 1 && S == 1) PMFCHK(epoch_open(c, o));
+        PMFCHK(pass_chunk(s));
+        in_flight = true;
+      }
+    }
+    HIPCHK(hipEventSynchronize(c->ev_host));
+    loss = c->h_loss[0] + c->h_loss[1] + (c->h_loss[2] + c->h_loss[3]);
+    if (getenv("PMF_DEBUG_LOSS"))
+      fprintf(stderr, "[pmf rank %d] epoch %d: data %.10g xreg %.10g yreg %.10g layers %.10g (n_macro %lld, reg counts %d %d %d)\n", m.rank, epoch,
+              c->h_loss[0], c->h_loss[1], c->h_loss[2], c->h_loss[3], (long long)c->n_macro, rc.c[0], rc.c[1], rc.c[2]);
+    if (getenv("PMF_DEBUG_LOSS") && !std::isfinite(c->h_loss[2])) {
+      HIPCHK(hipDeviceSynchronize());
+      auto dump = [&](const char *nm, const float *d, int64_t cnt) {
+        std::vector<float> h((size_t)cnt);
+        (void)hipMemcpy(h.data(), d, sizeof(float) * (size_t)cnt, hipMemcpyDeviceToHost);
+        double mn = 1e300, mx = -1e300; int64_t bad = 0, first = -1;
+        for (int64_t e = 0; e < cnt; ++e) { if (!std::isfinite(h[(size_t)e])) { if (first < 0) first = e; ++bad; } else { mn = std::min<double>(mn, h[(size_t)e]); mx = std::max<double>(mx, h[(size_t)e]); } }
+        fprintf(stderr, "[pmf rank %d]   %s: n %lld min %g max %g nonfinite %lld (first at %lld)\n", m.rank, nm, (long long)cnt, mn, mx, (long long)bad, (long long)first);
+      };
+      dump("Y", c->P[1].p, c->P[1].n); dump("gY", c->P[1].g, c->P[1].n); dump("accY", c->P[1].acc, c->P[1].n);
+      if (c->ard_beta) { dump("beta", c->ard_beta, c->P[1].n); dump("alpha", c->ard_alpha, c->N); }
+      std::vector<double> rp((size_t)rc.c[1]);
+      (void)hipMemcpy(rp.data(), c->reg_partial + REG_SLOTS, sizeof(double) * rp.size(), hipMemcpyDeviceToHost);
+      for (size_t q = 0; q < rp.size(); ++q) if (!std::isfinite(rp[q])) fprintf(stderr, "[pmf rank %d]   yreg partial %zu = %g\n", m.rank, q, rp[q]);
+    }
     if (res->loss_trace && n < res->trace_cap) res->loss_trace[n] = loss;
     ++n;
     last_epoch = epoch;
@@ -1871,6 +2467,12 @@ extern "C" int pmf_fit(pmf_ctx *c, const pmf_fit_opts *o, pmf_fit_result *res) {
     }
     prev = loss;
   }
+  // a speculative data pass (and its collectives: every rank took the same decision on the same loss, so every rank
+  // enqueued them) may still be running: the call returns with both streams idle
+  (void)in_flight;
+  HIPCHK(hipStreamSynchronize(c->stream));
+  if (cm) HIPCHK(hipStreamSynchronize(m.stream));
+  harvest_events(c);
   res->term_code = term;
   res->epochs = last_epoch;
   res->n_trace = res->loss_trace ? std::min(n, res->trace_cap) : 0;
@@ -1979,7 +2581,7 @@ extern "C" int pmf_stats(pmf_ctx *c, int use_factors, float *col_n, float *col_s
     case 4: kst = k_stats<4>; break;
     default: return pmf_fail("unsupported KB=%d", c->KB);
   }
-  HIPCHK(hipFuncSetAttribute((const void *)kst, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  PMFCHK(ensure_dyn_lds(c, (const void *)kst, lds));
   hipLaunchKernelGGL(kst, dim3(gx, (unsigned)gy), dim3(64), lds, c->stream, a);
   HIPCHK(hipGetLastError());
   HIPCHK(hipStreamSynchronize(c->stream));

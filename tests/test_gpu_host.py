@@ -149,3 +149,4 @@ def test_plain_c_host_runs(tmp_path):
     r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, (r.stdout, r.stderr)
     assert "term_code" in r.stdout
+    assert "one-rank RCCL communicator: rank 0 of 1, transport 1" in r.stdout and "bit-identical" in r.stdout, r.stdout
