@@ -172,6 +172,11 @@ int pmf_set_optimizer(pmf_ctx *ctx, int kind, float lr, float eps, float beta1, 
 int pmf_set_lr(pmf_ctx *ctx, float lr);
 int pmf_get_lr(pmf_ctx *ctx, float *lr);
 int pmf_reset_optimizer_state(pmf_ctx *ctx);
+/* the optimizer's per-parameter state in the parameter's own shape (view: batch view for logdelta / theta): AdaGrad's
+ * `acc` (Flux.Optimise.AdaGrad, applied through src/optimizers.jl:6-13; starts at eps) or Adam's second moment, and
+ * Adam's first moment.  The state lives as long as the optimizer object does in the reference: across the mf_fit! calls
+ * of one mf_fit_adapt_lr! (src/fit.jl:55-69), whatever is re-marshalled in between. */
+int pmf_get_opt_state(pmf_ctx *ctx, int which, int view, float *acc, float *mom);
 
 /* MF.fit!(model.matfac, model.data; ...) as called from mf_fit! (src/fit.jl:24-36) */
 int pmf_fit(pmf_ctx *ctx, const pmf_fit_opts *opts, pmf_fit_result *result);

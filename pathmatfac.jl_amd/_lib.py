@@ -49,7 +49,7 @@ EXPORTS = [
     "pmf_grad_device_ptr", "pmf_get_grad", "pmf_forward", "pmf_stats", "pmf_kernel_time", "pmf_synth_data",
     "pmf_set_precision", "pmf_get_precision",
     "pmf_comm_get_unique_id", "pmf_comm_init", "pmf_comm_init_host", "pmf_comm_destroy", "pmf_comm_set_chunks",
-    "pmf_comm_info", "pmf_comm_allreduce",
+    "pmf_comm_info", "pmf_comm_allreduce", "pmf_get_opt_state",
 ]
 
 COMM_ID_BYTES = 128
@@ -348,6 +348,20 @@ class Context:
             out = np.zeros(self.view_shapes[view], np.float32, order="F")
         self._chk(self.lib.pmf_get_grad(self._h, PARAM[which], int(view), _fp(out)))
         return out
+
+    def get_opt_state(self, which, view=0):
+        """(acc, mom) of a parameter group in the parameter's shape (pmf_get_opt_state)."""
+        if which == "X":
+            shape = (self.K, self.M)
+        elif which == "Y":
+            shape = (self.K, self.N)
+        elif which in ("logsigma", "mu"):
+            shape = (self.N,)
+        else:
+            shape = self.view_shapes[view]
+        acc, mom = np.zeros(shape, np.float32, order="F"), np.zeros(shape, np.float32, order="F")
+        self._chk(self.lib.pmf_get_opt_state(self._h, PARAM[which], int(view), _fp(acc), _fp(mom)))
+        return acc, mom
 
     def forward(self):
         Z = np.zeros((self.M, self.N), np.float32, order="F")

@@ -2504,6 +2504,31 @@ extern "C" int pmf_get_grad(pmf_ctx *c, int which, int view, float *out) {
   return 0;
 }
 
+// optimizer state of one parameter group in the reference's shape: AdaGrad's accumulator (or Adam's second moment)
+// and Adam's first moment (Flux.Optimise.AdaGrad.acc / Adam's (mt, vt), reached through src/optimizers.jl:6-13)
+extern "C" int pmf_get_opt_state(pmf_ctx *c, int which, int view, float *acc, float *mom) {
+  PMFCHK(ctx_bind(c));
+  if (which < 0 || which > 5) return pmf_fail("bad parameter id %d", which);
+  if (!c->state_init) return pmf_fail("optimizer state not initialised yet (no epoch has run since pmf_set_optimizer)");
+  HIPCHK(hipStreamSynchronize(c->stream));
+  const ParamBuf &b = c->P[which];
+  if (which <= 1) {
+    const int64_t n = which == 0 ? c->M : c->N;
+    if (acc) PMFCHK(download_padded(c, acc, b.acc, n));
+    if (mom) PMFCHK(download_padded(c, mom, b.mom, n));
+    return 0;
+  }
+  int64_t off = 0, n = c->N;
+  if (which >= 4) {
+    if (view < 0 || view >= c->n_bv) return pmf_fail("batch view %d out of range", view);
+    off = c->val_off[view];
+    n = c->val_off[view + 1] - off;
+  }
+  if (acc) HIPCHK(hipMemcpy(acc, b.acc + off, sizeof(float) * (size_t)n, hipMemcpyDeviceToHost));
+  if (mom) HIPCHK(hipMemcpy(mom, b.mom + off, sizeof(float) * (size_t)n, hipMemcpyDeviceToHost));
+  return 0;
+}
+
 static int run_forward(pmf_ctx *c, float *Zdev, int synth, uint64_t seed, float noise, float frac_nan, int64_t nRB = 0) {
   PMFCHK(check_ready(c));
   PMFCHK(prepare(c));

@@ -79,12 +79,14 @@ def init_theta_(model, capacity=int(10e8), max_epochs=500, lr_theta=1.0, verbosi
 
 def init_factors_(model, verbosity=1, print_prefix="", history=None, lr=1.0, capacity=10 ** 8, max_epochs=1000,
                   init_factors_method="adagrad", rel_tol=1e-5, abs_tol=1e-5, **kwargs):
-    """init_factors! (src/fit.jl:249-288), AdaGrad branch (the L-BFGS branch is out of scope)."""
+    """init_factors! (src/fit.jl:249-288), AdaGrad branch (the L-BFGS branch is out of scope).
+    `rel_tol` / `abs_tol` are captured here as in the reference (:256-257) and belong to the L-BFGS branch only: the
+    AdaGrad branch (:280-284) does not pass them on, so that stage stops on MF.fit!'s own default tolerances."""
     if init_factors_method != "adagrad":
         raise NotImplementedError("init_factors_method='lbfgs' is out of scope (src/fit_lbfgs.jl)")
     mf_fit_adapt_lr_(model, capacity=capacity, update_X=True, update_Y=True, lr=lr, min_lr=0.05,
                      max_epochs=max_epochs, verbosity=verbosity, print_prefix=print_prefix + "    ",
-                     history=history, rel_tol=rel_tol, abs_tol=abs_tol, **kwargs)
+                     history=history, **kwargs)
     history_(history, name="init_factors")
 
 
@@ -371,6 +373,36 @@ def reweight_eb_(reg, P, mixture_p=1.0):
     elif isinstance(reg, _R.CompositeRegularizer):
         for r, p in zip(reg.regularizers, reg.mixture_p):
             reweight_eb_(r, P, mixture_p=p * mixture_p)
+    elif isinstance(reg, _R.ColParamReg):
+        # regularizers.jl:490-497 on the layer's vector (logsigma of ColScale / mu of ColShift, :510-519): per view range,
+        # centre = mean, weight = p * (0.1 + 0.5) / (0.1 + 0.5 var), Julia's `var` = sample variance (n - 1)
+        v = np.asarray(P.logsigma if isinstance(P, ColScale) else P.mu if isinstance(P, ColShift) else P, dtype=np.float64)
+        centers, weights = [], []
+        for r in reg.col_ranges:
+            x = v[r.slice0()]
+            var = float(np.var(x, ddof=1)) if x.size > 1 else float("nan")
+            centers.append(float(np.mean(x)))
+            weights.append(float(np.float32(mixture_p) * np.float32(0.1 + 0.5) / (np.float32(0.1) + np.float32(0.5) * np.float32(var))))
+        reg.centers, reg.weights = tuple(centers), tuple(weights)
+    elif isinstance(reg, _R.BatchArrayReg):
+        # regularizers.jl:818-838 on the layer's BatchArray (logdelta of BatchScale / theta of BatchShift, :868-875): per
+        # view and row batch, centre = mean over the view's columns, weight = p / var; a non-finite weight (one column, or
+        # zero variance) becomes 1 + 0.5 * (#columns): the posterior mean of a Gamma(1, 1) precision
+        ba = P.logdelta if isinstance(P, BatchScale) else P.theta if isinstance(P, BatchShift) else P
+        centers, weights = [], []
+        for vals, cr in zip(ba.values, ba.col_ranges):
+            x = np.asarray(vals, dtype=np.float64)
+            with np.errstate(divide="ignore", invalid="ignore"):
+                var = np.var(x, axis=1, ddof=1) if x.shape[1] > 1 else np.full(x.shape[0], np.nan)
+                w = (mixture_p / var).astype(np.float32)
+            w[~np.isfinite(w)] = np.float32(1 + 0.5 * len(cr))
+            centers.append(np.mean(x, axis=1).astype(np.float32))
+            weights.append(w)
+        reg.centers, reg.weights = tuple(centers), tuple(weights)
+    elif isinstance(reg, SequenceReg):
+        # regularizers.jl:928-932: zip over (regs, layers); P is the ViewableComposition
+        for i, r in enumerate(reg.regs):
+            reweight_eb_(r.reg if isinstance(r, _R.FrozenRegularizer) else r, P.unwrapped(i + 1), mixture_p=mixture_p)
     # pure functions (x -> 0) and FeatureSetARDReg have no adjustable weights (regularizers.jl:941-943)
 
 
@@ -462,6 +494,8 @@ def basic_fit_reg_weight_eb_(model, capacity=int(10e8), lr=1.0, max_epochs=1000,
     if isinstance(sr, SequenceReg):
         unfreeze_reg_(sr, [1, 2, 3, 4])                                        # :709
     mf.X_reg, mf.Y_reg = orig_X_reg, orig_Y_reg
+    if isinstance(sr, SequenceReg):
+        reweight_eb_(sr, mf.col_transform)                                     # :712
     reweight_eb_(mf.X_reg, mf.X)                                               # :713
     reweight_eb_(mf.Y_reg, mf.Y)                                               # :714
     history_(history, name="reweight_eb")

@@ -96,6 +96,15 @@ def make_problem(M, N, K, seed=0, bernoulli_frac=0.0, poisson_frac=0.0, n_views=
         p["yreg"] = [dict(kind="ard", start1=[g[0] for g in view_ranges], stop1=[g[1] for g in view_ranges],
                           a=np.full(len(view_ranges), 1.001, np.float32),
                           b=np.full(len(view_ranges), 0.001, np.float32), p=1.0)]
+    elif yreg == "l2":
+        p["yreg"] = [dict(kind="l2", w=(0.5 + rng.random(K)).astype(np.float32), p=1.0)]
+    elif yreg == "ard_gap":
+        # ARDRegularizer with distinct (alpha, beta) per view range and one view left uncovered (regularizers.jl:546-585
+        # loops over its col_ranges only; the library encodes "not regularized" as alpha = -0.5)
+        keep = [g for i, g in enumerate(view_ranges) if i != 1 or len(view_ranges) == 1]
+        p["yreg"] = [dict(kind="ard", start1=[g[0] for g in keep], stop1=[g[1] for g in keep],
+                          a=(1.001 + 0.5 * rng.random(len(keep))).astype(np.float32),
+                          b=(0.001 + 0.01 * rng.random(len(keep))).astype(np.float32), p=1.0)]
     elif yreg == "fsard":
         alpha = np.full(N, 1.001, np.float32)
         beta = (0.001 * (0.8 + 2.0 * rng.random((K, N)) * (rng.random((K, N)) < 0.2))).astype(np.float32)
