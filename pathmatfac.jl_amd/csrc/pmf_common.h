@@ -1,0 +1,234 @@
+// pmf_common.h -- what the translation units of libpmf_hip.so share: the kernels' argument structs, the device layout of
+// the data matrix, small device helpers, and the host-side launchers each kernel file exports.  The library is built
+// from several translation units so that they compile in parallel (csrc/Makefile):
+//   pmf_hip.hip        C ABI, small kernels, work split, epoch loop, communicator
+//   pmf_k_fused.hip    pmf_fused_kernel (pmf_fused.hip.inc), once per (K blocks, row blocks per wave)
+//   pmf_k_sb.hip       pmf_fused_sb_kernel + k_sb_split (pmf_fused_sb.hip.inc), once per K-block count
+//   pmf_k_layers.hip   pmf_layer_kernel + k_layer_map (pmf_layers.hip.inc)
+#ifndef PMF_COMMON_H
+#define PMF_COMMON_H
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <unordered_map>
+
+#include "../../include/pmf_hip.h"
+
+// ---- errors (defined in pmf_hip.hip)
+int pmf_fail(const char *fmt, ...);
+#define HIPCHK(x)                                                                                    \
+  do {                                                                                               \
+    hipError_t e_ = (x);                                                                             \
+    if (e_ != hipSuccess) return pmf_fail("%s failed: %s (%s:%d)", #x, hipGetErrorString(e_), __FILE__, __LINE__); \
+  } while (0)
+#define PMFCHK(x)          \
+  do {                     \
+    int r_ = (x);          \
+    if (r_ < 0) return r_; \
+  } while (0)
+
+// largest dynamic-LDS size set so far per kernel on one context's device (hipFuncSetAttribute is per device)
+typedef std::unordered_map<const void *, size_t> PmfDynLds;
+int pmf_ensure_dyn_lds(PmfDynLds *cache, const void *kern, size_t lds);
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define PMF_MAXV 16
+#define PMF_BN 32      // columns per tile
+#define PMF_DPAD 64    // D is padded with NaN columns to a multiple of this
+
+// Device layout of the data matrix.  The library owns its copy of D, so it is free to re-lay it out once at upload:
+// D is stored as 32 x 32 tiles, tile (rb, cb) at ((cb * nRB) + rb) * 1024 floats (the 8 row blocks of a workgroup's
+// panel are contiguous for one column block), and INSIDE a tile in the register order of the MFMA accumulator:
+// float offset q*256 + lane*4 + e holds element (i = lane & 31, j = rowmap(4q + e, lane >> 5)).  A wave therefore
+// streams its tile with four global_load_dwordx4, each instruction 1 KiB contiguous.  Rows / columns beyond M / N
+// are NaN (= missing), so the kernel needs no bounds checks on D.
+__host__ __device__ __forceinline__ int64_t pmf_d_off(int64_t i, int64_t j, int64_t nRB) {
+  const int il = (int)(i & 31), jl = (int)(j & 31);
+  const int h = (jl >> 2) & 1;
+  const int r = (jl & 3) + 4 * (jl >> 3);
+  return (((j >> 5) * nRB) + (i >> 5)) * 1024 + (r >> 2) * 256 + (h * 32 + il) * 4 + (r & 3);
+}
+
+struct ViewDesc {
+  int64_t c0;       // 0-based first column of the view
+  int64_t c1;       // one past the last column
+  int64_t tab_off;  // offset of the view's table in btab (float2 {delta, theta}, nb x Nv column-major)
+  int32_t nb;
+  int32_t pad;
+};
+
+struct FusedArgs {
+  const float *D;       // tile-major, see pmf_d_off; nRB row blocks x roundup(N,64)/32 column blocks
+  const uint32_t *tflags;  // per 32x32 tile (same order as the tiles of D): 1 = every entry finite (k_tile_flags)
+  int64_t nRB;
+  const float *X;
+  const float *Y;
+  float *gX;
+  float *gY;            // (unused by the kernel: gY is produced by k_gy_reduce from the private slabs)
+  float *gy_slabs;      // [gridDim.x][Kp x N] per-workgroup private partial sums of gY
+  int64_t slab_stride;  // Kp * N
+  int64_t n_rp;         // row panels
+  int64_t n_tiles;      // n_rp * (column tiles): the kernel's work
+  const int64_t *wg_begin;  // [grid + 1] first work item of every workgroup's range (cost-balanced on the host)
+  int32_t tps;          // column tiles per segment (the last segment may have fewer)
+  int32_t n_ct;         // column tiles
+  const float4 *colp;   // per column {sigma, mu, weight, meta}; meta = kind | (view+1)<<2
+  const int32_t *bor;   // n_bv x M
+  const float2 *btab;
+  const float2 *btd;    // dense per-column batch table [N padded][16] {delta, theta} (slot 15 = identity); null = not available
+  int32_t n_bv;         // batch views
+  double *loss_partial; // one slot per workgroup
+  int64_t M, N;
+  int32_t n_cseg;
+  int32_t want_gx, want_gy;
+  unsigned long long *stamps;  // diagnostic build only (PMF_STAMPS)
+  int32_t dbg;          // development ablation bits (PMF_DEBUG_FLAGS): 1 no slab reduce, 2 no D loads, 4 no epilogue, 8 no gY atomics
+  const ViewDesc *views;   // device array [n_bv] (a by-value array indexed per lane would be copied to scratch)
+  const char *Xsb, *Ysb;   // split-bf16 operand images of X and sigma*Y (pmf_fused_sb.hip.inc); null on the exact-f32 path
+  // One launch covers the column tiles [ct0, ct0 + n_ct) (a "chunk": the whole matrix on one GPU; with several ranks the
+  // columns are walked in a few chunks so that the all-reduce of a finished chunk's grad(Y) overlaps the next chunk).
+  int32_t ct0;
+  // grad(X) without atomics: every piece STORES its 32*NW*RBW x Kp partial sum to a slot of its own; k_gx_reduce sums
+  // the slots of a row panel in a fixed order (bitwise reproducible gX).  Slot of a workgroup's p-th piece =
+  // piece_base[wg] + p (pieces are numbered in the order of the work sequence; built on the host with the work split).
+  float *gx_part;
+  const int32_t *piece_base;   // [grid]
+  int64_t gx_slot_stride;      // floats per slot = BM * Kp
+};
+
+__device__ __forceinline__ int pmf_rowmap(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+__device__ __forceinline__ bool pmf_finite(float y) { return fabsf(y) <= 3.402823466e38f; }  // false for NaN, +-Inf
+
+// loss and dloss/dz of one entry.  SELF-SPECIFIED noise models (MatFac is un-vendored):
+//   normal 0.5 w (z-y)^2 ; bernoulli w (softplus(z) - y z) ; poisson w (exp(z) - y z)
+__device__ __forceinline__ void pmf_noise(int kind, float z, float y, float w, float &l, float &g) {
+  if (kind == PMF_NOISE_NORMAL) {
+    const float d = z - y;
+    g = w * d;
+    l = 0.5f * g * d;
+  } else if (kind == PMF_NOISE_BERNOULLI) {
+    const float e = __expf(-fabsf(z));
+    const float sp = fmaxf(z, 0.f) + __logf(1.f + e);
+    const float r = __frcp_rn(1.f + e);
+    const float sg = z >= 0.f ? r : e * r;
+    l = w * (sp - y * z);
+    g = w * (sg - y);
+  } else {
+    const float e = __expf(z);
+    l = w * (e - y * z);
+    g = w * (e - y);
+  }
+}
+
+#define PMF_SCHED_FENCE() asm volatile("" ::: "memory")
+
+// Streaming (non-temporal) 16-B accesses for data that is touched once per pass (the D tiles, the private gY slab
+// entries): they do not displace the Y tiles of the column segment from the XCD's L2.
+typedef float pmf_f32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 pmf_load_stream(const float4 *p) {
+  const pmf_f32x4 v = __builtin_nontemporal_load(reinterpret_cast<const pmf_f32x4 *>(p));
+  return make_float4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ void pmf_store_stream(float4 *p, const float4 &v) {
+  const pmf_f32x4 vv = {v.x, v.y, v.z, v.w};
+  __builtin_nontemporal_store(vv, reinterpret_cast<pmf_f32x4 *>(p));
+}
+
+// Diagnostic build only (-DPMF_STAMPS): per-phase shader-cycle totals, one row of 16 counters per workgroup,
+// written to a buffer nothing else reads (cdna_hip_programming.md section 7, "In-kernel stamps").
+#ifdef PMF_STAMPS
+#define PMF_STAMP(slot)                                                                      \
+  do {                                                                                       \
+    unsigned long long t_;                                                                   \
+    __builtin_amdgcn_sched_barrier(0);                                                       \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");               \
+    __builtin_amdgcn_sched_barrier(0);                                                       \
+    st_acc[slot] += t_ - st_prev;                                                            \
+    st_prev = t_;                                                                            \
+  } while (0)
+#else
+#define PMF_STAMP(slot) do { } while (0)
+#endif
+
+
+// ---- split-bf16 operand images (pmf_fused_sb.hip.inc)
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+
+// KB = K blocks of 32 factors: 1 (K <= 32) or 2 (K <= 64).  An image is [32 rows][32 KB] bf16 = 2 KB KiB, rows of 64 KB bytes.
+// Chunk swizzle f(row) per row length (both kinds of read conflict-free, checked with the bank rules of
+// MI355X_MICROARCH.md "LDS" and by SQ_LDS_BANK_CONFLICT = 0):
+//   64-B rows  : (row >> 2) & 3        (four rows per 256-B bank window; a transposed read takes four whole rows)
+//   128-B rows : x ^ ((x & 1) << 2), x = (row >> 1) & 7
+template <int KB>
+__host__ __device__ __forceinline__ int pmf_sb_f(int row) {
+  if (KB == 1) return (row >> 2) & 3;
+  const int x = (row >> 1) & 7;
+  return x ^ ((x & 1) << 2);
+}
+template <int KB>
+__host__ __device__ __forceinline__ int pmf_sb_off(int row, int ch) { return 64 * KB * row + 16 * (ch ^ pmf_sb_f<KB>(row)); }
+
+template <int KB>
+struct SbCfg {
+  static constexpr int NW = 8, Kp = 32 * KB, SLAB = 32 * Kp;
+  static constexpr int IMG = 2048 * KB;    // bytes of one [32][Kp] bf16 image
+  static constexpr int BLK = 3 * IMG;      // global block of 32 rows: hi image, mid image, lo image
+  static constexpr int LDSP = 2 * IMG;     // the part every product reads (hi, mid); the lo image only feeds the forward
+  static constexpr size_t lds_bytes = 2 * LDSP + IMG + NW * LDSP + NW * SLAB * 4 + 8 * PMF_BN * 4 + 16 + 8 * NW;
+  // batch-layer variants add the tile's dense batch table [32 columns][16] float2 and, per wave, [n_bv views][32 rows] batch ids
+  static constexpr size_t lds_batch(int n_bv) { return PMF_BN * 16 * sizeof(float2) + (size_t)NW * n_bv * 32; }
+  static constexpr int max_bv = KB == 1 ? PMF_MAXV : (int)((160 * 1024 - lds_bytes - PMF_BN * 16 * sizeof(float2)) / (NW * 32));
+};
+
+// src: [n][Kp] f32 (rows = samples of X or columns of Y, K padded to Kp); scale = colp (sigma in .x) or null.
+// out: one block per 32 rows: hi, mid and lo image.  Rows >= n are zero.  One thread per (row, 16-B chunk).
+struct SbSplitArgs {
+  const float *src;
+  const float4 *colp;
+  int64_t n, nblk;
+  char *out;
+};
+
+// ---- layer pass (pmf_layers.hip.inc)
+#define PMF_LS 2   // column tiles per unit (4 was measured: more per-tile state in registers, more spills, 19.6 vs 13.5 ms)
+
+struct LayerPassArgs {
+  const float *D;
+  int64_t nRB;
+  const float *X, *Y;
+  const float4 *colp;
+  const int32_t *bor;      // n_bv x M row -> batch (or -1)
+  const float2 *btd;       // dense batch table [N padded to 32][16] {delta, theta}; null when there are no batch views
+  float2 *LG;              // [N][16] {S_G, S_Q}, zeroed by the host before the launch
+  double *loss_partial;    // one per workgroup; null = the loss is computed elsewhere (combined epochs)
+  int64_t M, N;
+  int32_t n_bv, n_ct, n_rp, n_seg, R;
+};
+
+struct LayerMapArgs {
+  const float2 *LG;
+  const float2 *btd;
+  const float4 *colp;
+  float *g_logsigma, *g_mu, *g_logdelta, *g_theta;   // any may be null
+  int64_t N;
+  int32_t n_bv;
+  ViewDesc views[PMF_MAXV];
+  int64_t val_off[PMF_MAXV];
+};
+
+// ---- launchers exported by the kernel files
+int pmf_launch_fused_exact_11(PmfDynLds *cache, hipStream_t stream, const FusedArgs &a, int grid, bool batch, bool mixed);
+int pmf_launch_fused_exact_12(PmfDynLds *cache, hipStream_t stream, const FusedArgs &a, int grid, bool batch, bool mixed);
+int pmf_launch_fused_exact_21(PmfDynLds *cache, hipStream_t stream, const FusedArgs &a, int grid, bool batch, bool mixed);
+int pmf_launch_fused_exact_31(PmfDynLds *cache, hipStream_t stream, const FusedArgs &a, int grid, bool batch, bool mixed);
+int pmf_launch_fused_exact_41(PmfDynLds *cache, hipStream_t stream, const FusedArgs &a, int grid, bool batch, bool mixed);
+int pmf_launch_fused_sb_1(PmfDynLds *cache, hipStream_t stream, const FusedArgs &a, int grid, bool batch, bool mixed, bool want_gx, bool want_gy);
+int pmf_launch_fused_sb_2(PmfDynLds *cache, hipStream_t stream, const FusedArgs &a, int grid, bool batch, bool mixed, bool want_gx, bool want_gy);
+int pmf_launch_sb_split_1(hipStream_t stream, const SbSplitArgs &a);
+int pmf_launch_sb_split_2(hipStream_t stream, const SbSplitArgs &a);
+int pmf_launch_layer_pass(PmfDynLds *cache, hipStream_t stream, int KB, int lnw, bool mixed, int grid, const LayerPassArgs &a);
+int pmf_launch_layer_map(hipStream_t stream, const LayerMapArgs &m);
+#endif

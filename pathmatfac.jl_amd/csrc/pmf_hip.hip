@@ -15,16 +15,13 @@
 #include <unordered_map>
 #include <vector>
 
-#include "../../include/pmf_hip.h"
-#include "pmf_fused.hip.inc"
-#include "pmf_fused_sb.hip.inc"
-#include "pmf_layers.hip.inc"
+#include "pmf_common.h"
 
 // ------------------------------------------------------------------------------------------------
 // error handling
 // ------------------------------------------------------------------------------------------------
 static thread_local std::string g_err;
-static int pmf_fail(const char *fmt, ...) {
+int pmf_fail(const char *fmt, ...) {
   char buf[1024];
   va_list ap;
   va_start(ap, fmt);
@@ -33,17 +30,6 @@ static int pmf_fail(const char *fmt, ...) {
   g_err = buf;
   return -1;
 }
-#define HIPCHK(x)                                                                                    \
-  do {                                                                                               \
-    hipError_t e_ = (x);                                                                             \
-    if (e_ != hipSuccess) return pmf_fail("%s failed: %s (%s:%d)", #x, hipGetErrorString(e_), __FILE__, __LINE__); \
-  } while (0)
-#define PMFCHK(x)          \
-  do {                     \
-    int r_ = (x);          \
-    if (r_ < 0) return r_; \
-  } while (0)
-
 extern "C" const char *pmf_last_error(void) { return g_err.c_str(); }
 extern "C" int pmf_version(void) { return 1; }
 
@@ -169,7 +155,7 @@ struct pmf_ctx {
   size_t scratch_bytes = 0;
   // largest dynamic-LDS size set so far per kernel ON THIS CONTEXT'S DEVICE (hipFuncSetAttribute is per device: a
   // process-wide cache would leave a second GPU's kernels without the attribute)
-  std::unordered_map<const void *, size_t> dyn_lds;
+  PmfDynLds dyn_lds;
 };
 
 #define REG_SLOTS 1024
@@ -222,13 +208,14 @@ static void param_free(ParamBuf &b) {
   b.n = 0;
 }
 
-static int ensure_dyn_lds(pmf_ctx *c, const void *kern, size_t lds) {
-  auto it = c->dyn_lds.find(kern);
-  if (it != c->dyn_lds.end() && it->second >= lds) return 0;
+int pmf_ensure_dyn_lds(PmfDynLds *cache, const void *kern, size_t lds) {
+  auto it = cache->find(kern);
+  if (it != cache->end() && it->second >= lds) return 0;
   HIPCHK(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  c->dyn_lds[kern] = lds;
+  (*cache)[kern] = lds;
   return 0;
 }
+static int ensure_dyn_lds(pmf_ctx *c, const void *kern, size_t lds) { return pmf_ensure_dyn_lds(&c->dyn_lds, kern, lds); }
 
 static int ensure_scratch(pmf_ctx *c, size_t bytes) {
   if (c->scratch_bytes >= bytes) return 0;
@@ -1572,28 +1559,6 @@ static int compute_work_split(pmf_ctx *c, WorkSplit &ws, int grid, int64_t n_rp,
   return 0;
 }
 
-template <int KB, int NW, int RBW>
-static int launch_fused_t(pmf_ctx *c, const FusedArgs &a, int grid, bool batch, bool mixed) {
-  using Cfg = FusedCfg<KB, NW, RBW>;
-  const size_t lds = Cfg::lds_bytes + (batch ? Cfg::lds_batch_extra : 0);
-  // gradient mode (compile-time in the kernel): 0 both, 1 grad(X) only, 2 grad(Y) only, 3 run-time flags
-  int gm = a.dbg != 0 ? 3 : (a.want_gx && a.want_gy ? 0 : (a.want_gx ? 1 : (a.want_gy ? 2 : 3)));
-  void (*kern)(const FusedArgs) = nullptr;
-  const int bmode = !batch ? 0 : (a.btd ? 1 : 2);
-  if (bmode == 2 && gm != 0) gm = 3;   // the gather fallback (> 15 batches per view) has no single-gradient variants
-#define PMF_PICK_G(BM, MX) (gm == 0 ? pmf_fused_kernel<KB, NW, RBW, BM, MX, 0> : gm == 1 ? pmf_fused_kernel<KB, NW, RBW, BM, MX, 1> : \
-                            gm == 2 ? pmf_fused_kernel<KB, NW, RBW, BM, MX, 2> : pmf_fused_kernel<KB, NW, RBW, BM, MX, 3>)
-  if (bmode == 0) kern = mixed ? PMF_PICK_G(0, true) : PMF_PICK_G(0, false);
-  else if (bmode == 1) kern = mixed ? PMF_PICK_G(1, true) : PMF_PICK_G(1, false);
-  else if (gm == 0) kern = mixed ? pmf_fused_kernel<KB, NW, RBW, 2, true, 0> : pmf_fused_kernel<KB, NW, RBW, 2, false, 0>;
-  else kern = mixed ? pmf_fused_kernel<KB, NW, RBW, 2, true, 3> : pmf_fused_kernel<KB, NW, RBW, 2, false, 3>;
-#undef PMF_PICK_G
-  PMFCHK(ensure_dyn_lds(c, (const void *)kern, lds));
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * NW), lds, c->stream, a);
-  HIPCHK(hipGetLastError());
-  return 0;
-}
-
 #ifdef PMF_STAMPS
 static unsigned long long *g_stamps = nullptr;
 extern "C" int pmf_debug_stamps(unsigned long long *out, int n) {
@@ -1747,19 +1712,13 @@ static int prepare_fused_pass(pmf_ctx *c, const FusedGeom &g, bool want_gx, bool
 // chunk of the previous epoch may not have run yet when an earlier chunk is launched, pmf_fit)
 static int sb_split_x(pmf_ctx *c) {
   SbSplitArgs sx = {c->P[0].p, nullptr, c->M, c->nRB, c->xsb};
-  if (c->KB == 1) k_sb_split<1><<<nblocks(c->nRB * 32 * 4, 256), 256, 0, c->stream>>>(sx);
-  else k_sb_split<2><<<nblocks(c->nRB * 32 * 8, 256), 256, 0, c->stream>>>(sx);
-  HIPCHK(hipGetLastError());
-  return 0;
+  return c->KB == 1 ? pmf_launch_sb_split_1(c->stream, sx) : pmf_launch_sb_split_2(c->stream, sx);
 }
 static int sb_split_y(pmf_ctx *c, int64_t ct0, int64_t nct) {
   const size_t blk = c->KB == 1 ? SbCfg<1>::BLK : SbCfg<2>::BLK;
   const int64_t col0 = ct0 * 32;
   SbSplitArgs sy = {c->P[1].p + col0 * c->Kp, c->colp + col0, c->N - col0, nct, c->ysb + (size_t)ct0 * blk};
-  if (c->KB == 1) k_sb_split<1><<<nblocks(nct * 32 * 4, 256), 256, 0, c->stream>>>(sy);
-  else k_sb_split<2><<<nblocks(nct * 32 * 8, 256), 256, 0, c->stream>>>(sy);
-  HIPCHK(hipGetLastError());
-  return 0;
+  return c->KB == 1 ? pmf_launch_sb_split_1(c->stream, sy) : pmf_launch_sb_split_2(c->stream, sy);
 }
 
 // One chunk of the data pass: the fused kernel over column tiles [ct0, ct0 + nct) and the fixed-order reduction of its
@@ -1821,26 +1780,16 @@ static int launch_fused_chunk(pmf_ctx *c, const FusedGeom &g, int s, bool want_g
   HIPCHK(hipEventRecord(ev.first, c->stream));
   int rc = 0;
   if (g.sb) {
-    void (*kern)(const FusedArgs) = nullptr;
-    // (the batch-layer variants exist with the per-tile noise-model dispatch only: MIXED = true also serves uniform models)
-#define PMF_SB_PICK_G(KBv, MX, BT) (want_gx && want_gy ? pmf_fused_sb_kernel<KBv, MX, true, true, BT>                                        \
-                                    : want_gx ? pmf_fused_sb_kernel<KBv, MX, true, false, BT> : pmf_fused_sb_kernel<KBv, MX, false, true, BT>)
-#define PMF_SB_PICK(KBv) (batch ? PMF_SB_PICK_G(KBv, true, true) : (c->mixed ? PMF_SB_PICK_G(KBv, true, false) : PMF_SB_PICK_G(KBv, false, false)))
-    kern = c->KB == 1 ? PMF_SB_PICK(1) : PMF_SB_PICK(2);
-#undef PMF_SB_PICK
-#undef PMF_SB_PICK_G
-    const size_t lds = (c->KB == 1 ? SbCfg<1>::lds_bytes : SbCfg<2>::lds_bytes) + (batch ? SbCfg<1>::lds_batch(c->n_bv) : 0);
-    PMFCHK(ensure_dyn_lds(c, (const void *)kern, lds));
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, c->stream, a);
-    HIPCHK(hipGetLastError());
+    rc = c->KB == 1 ? pmf_launch_fused_sb_1(&c->dyn_lds, c->stream, a, grid, batch, c->mixed, want_gx, want_gy)
+                    : pmf_launch_fused_sb_2(&c->dyn_lds, c->stream, a, grid, batch, c->mixed, want_gx, want_gy);
     c->sb_launches += 1;
   } else
   switch (c->KB * 10 + g.RBW) {
-    case 11: rc = launch_fused_t<1, 8, 1>(c, a, grid, batch, c->mixed); break;
-    case 12: rc = launch_fused_t<1, 8, 2>(c, a, grid, batch, c->mixed); break;
-    case 21: rc = launch_fused_t<2, 8, 1>(c, a, grid, batch, c->mixed); break;
-    case 31: rc = launch_fused_t<3, 4, 1>(c, a, grid, batch, c->mixed); break;
-    case 41: rc = launch_fused_t<4, 4, 1>(c, a, grid, batch, c->mixed); break;
+    case 11: rc = pmf_launch_fused_exact_11(&c->dyn_lds, c->stream, a, grid, batch, c->mixed); break;
+    case 12: rc = pmf_launch_fused_exact_12(&c->dyn_lds, c->stream, a, grid, batch, c->mixed); break;
+    case 21: rc = pmf_launch_fused_exact_21(&c->dyn_lds, c->stream, a, grid, batch, c->mixed); break;
+    case 31: rc = pmf_launch_fused_exact_31(&c->dyn_lds, c->stream, a, grid, batch, c->mixed); break;
+    case 41: rc = pmf_launch_fused_exact_41(&c->dyn_lds, c->stream, a, grid, batch, c->mixed); break;
     default: return pmf_fail("unsupported KB=%d", c->KB);
   }
   PMFCHK(rc);
@@ -1946,20 +1895,7 @@ static int launch_layer_pass(pmf_ctx *c, const pmf_fit_opts *o, bool with_loss) 
   a.D = c->D; a.nRB = c->nRB; a.X = c->P[0].p; a.Y = c->P[1].p; a.colp = c->colp; a.bor = c->bor;
   a.btd = c->n_bv > 0 ? c->btd : nullptr; a.LG = c->LG; a.loss_partial = with_loss ? c->loss_partial : nullptr;
   a.M = c->M; a.N = c->N; a.n_bv = c->n_bv; a.n_ct = (int)n_ct; a.n_rp = (int)n_rp; a.n_seg = (int)n_seg; a.R = (int)R;
-  void (*kern)(const LayerPassArgs) = nullptr;
-  size_t lds = 0;
-  switch (c->KB) {
-    case 1: kern = c->mixed ? pmf_layer_kernel<1, 8, true> : pmf_layer_kernel<1, 8, false>; lds = LayerCfg<1, 8>::lds_bytes; break;
-    case 2:
-      if (lnw == 8) { kern = c->mixed ? pmf_layer_kernel<2, 8, true> : pmf_layer_kernel<2, 8, false>; lds = LayerCfg<2, 8>::lds_bytes; }
-      else { kern = c->mixed ? pmf_layer_kernel<2, 4, true> : pmf_layer_kernel<2, 4, false>; lds = LayerCfg<2, 4>::lds_bytes; }
-      break;
-    case 3: kern = c->mixed ? pmf_layer_kernel<3, 4, true> : pmf_layer_kernel<3, 4, false>; lds = LayerCfg<3, 4>::lds_bytes; break;
-    default: kern = c->mixed ? pmf_layer_kernel<4, 4, true> : pmf_layer_kernel<4, 4, false>; lds = LayerCfg<4, 4>::lds_bytes; break;
-  }
-  PMFCHK(ensure_dyn_lds(c, (const void *)kern, lds));
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * lnw), lds, c->stream, a);
-  HIPCHK(hipGetLastError());
+  PMFCHK(pmf_launch_layer_pass(&c->dyn_lds, c->stream, c->KB, lnw, c->mixed, grid, a));
   LayerMapArgs m;
   memset(&m, 0, sizeof(m));
   const int fl = o->frozen_layers;
@@ -1969,9 +1905,7 @@ static int launch_layer_pass(pmf_ctx *c, const pmf_fit_opts *o, bool with_loss) 
   m.g_mu = (fl & 4) ? nullptr : c->P[3].g;
   m.g_theta = ((fl & 8) || c->n_bv == 0) ? nullptr : c->P[5].g;
   for (int v = 0; v < c->n_bv; ++v) { m.views[v] = c->views[v]; m.val_off[v] = c->val_off[v]; }
-  k_layer_map<<<nblocks(c->N, 256), 256, 0, c->stream>>>(m);
-  HIPCHK(hipGetLastError());
-  return 0;
+  return pmf_launch_layer_map(c->stream, m);
 }
 
 static int check_ready(pmf_ctx *c) {

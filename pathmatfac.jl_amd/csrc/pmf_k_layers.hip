@@ -1,0 +1,27 @@
+// pmf_k_layers.hip -- pmf_layer_kernel + k_layer_map (pmf_layers.hip.inc) and their launchers.
+#include "pmf_common.h"
+#include "pmf_layers.hip.inc"
+
+int pmf_launch_layer_pass(PmfDynLds *cache, hipStream_t stream, int KB, int lnw, bool mixed, int grid, const LayerPassArgs &a) {
+  void (*kern)(const LayerPassArgs) = nullptr;
+  size_t lds = 0;
+  switch (KB) {
+    case 1: kern = mixed ? pmf_layer_kernel<1, 8, true> : pmf_layer_kernel<1, 8, false>; lds = LayerCfg<1, 8>::lds_bytes; break;
+    case 2:
+      if (lnw == 8) { kern = mixed ? pmf_layer_kernel<2, 8, true> : pmf_layer_kernel<2, 8, false>; lds = LayerCfg<2, 8>::lds_bytes; }
+      else { kern = mixed ? pmf_layer_kernel<2, 4, true> : pmf_layer_kernel<2, 4, false>; lds = LayerCfg<2, 4>::lds_bytes; }
+      break;
+    case 3: kern = mixed ? pmf_layer_kernel<3, 4, true> : pmf_layer_kernel<3, 4, false>; lds = LayerCfg<3, 4>::lds_bytes; break;
+    default: kern = mixed ? pmf_layer_kernel<4, 4, true> : pmf_layer_kernel<4, 4, false>; lds = LayerCfg<4, 4>::lds_bytes; break;
+  }
+  PMFCHK(pmf_ensure_dyn_lds(cache, (const void *)kern, lds));
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * lnw), lds, stream, a);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+int pmf_launch_layer_map(hipStream_t stream, const LayerMapArgs &m) {
+  k_layer_map<<<(unsigned)((m.N + 255) / 256), 256, 0, stream>>>(m);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
