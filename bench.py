@@ -64,6 +64,8 @@ def main():
     ap.add_argument("--precision", default=os.environ.get("PMF_BENCH_PRECISION", "f32"), choices=["f32", "bf16x3"],
                     help="products of the fused data pass for the HEADLINE numbers: exact f32 MFMA (default) or the opt-in "
                          "split-bf16 kernel; the other mode is timed afterwards on the same data and reported beside it")
+    ap.add_argument("--store", default=os.environ.get("PMF_BENCH_STORE", "f32"), choices=["f32", "bf16"],
+                    help="storage type of the device copy of D (bf16: BASELINE configs[4]; read by the split-bf16 pass only)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "0") or 0)
@@ -137,7 +139,7 @@ def main():
     rng_x = np.random.default_rng(seed + 1 + rank)
     X_true = (rng_x.standard_normal((K, Ml)) * 0.3).astype(np.float32)
     X0 = (rng_x.standard_normal((K, Ml)) * 0.1).astype(np.float32)
-    ctx.set_data_device(None, Ml, N)                          # device-resident, library-owned
+    ctx.set_data_device(None, Ml, N, store=args.store)        # device-resident, library-owned
     ctx.set_factors(X_true, Y_true)
     ctx.set_col_params(np.zeros(N, np.float32), np.zeros(N, np.float32))
     ctx.set_batch_views([])
@@ -192,7 +194,9 @@ def main():
 
     dt, k_ms, k_n, losses, n_split = timed_run(args.precision)
     other = "bf16x3" if args.precision == "f32" else "f32"
-    dt2, k_ms2, k_n2, losses2, n_split2 = timed_run(other)   # the other arithmetic, same data, reported beside the headline
+    have_other = args.store == "f32"   # (a bf16-stored matrix is read by the split-bf16 pass only)
+    if have_other:
+        dt2, k_ms2, k_n2, losses2, n_split2 = timed_run(other)   # the other arithmetic, same data, reported beside the headline
     split_main = args.precision == "bf16x3" and n_split > 0
     cinfo = ctx.comm_info()
     n_chunks = max(1, cinfo["n_chunks"])
@@ -201,14 +205,16 @@ def main():
         # 6*M*N*K flops per epoch over the local rows; one launch of the fused kernel covers one of the
         # n_chunks column chunks of the pass (1 on a single GPU)
         flops_launch = 6.0 * Ml * N * K / n_chunks
+        dsz = 2.0 if args.store == "bf16" else 4.0      # bytes per entry of D in HBM
         achieved = flops_launch / (k_ms * 1e-3) / 1e12 if k_ms > 0 else 0.0
         out = {
             "metric": "fit_iters_per_sec", "value": args.steps / dt, "unit": "iters/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-            "dtype": "bf16x3 (split-bf16 products, f32 accumulation and elementwise)" if split_main else "f32",
+            "dtype": ("bf16x3 (split-bf16 products, f32 accumulation and elementwise" + (", D stored bf16)" if args.store == "bf16" else ")"))
+                     if split_main else "f32",
             "data": "synthetic",
-            "config": {"workload": f"fit! epoch on synthetic {M}x{N} f32 matrix, K={K}, Gaussian loss, "
+            "config": {"workload": f"fit! epoch on synthetic {M}x{N} matrix (D stored as {args.store}), K={K}, Gaussian loss, "
                                    f"group-reg X (32 groups) + featureset-ARD Y, {args.optimizer}; rows sharded over {world} GPU(s)",
                        "M": M, "N": N, "K": K, "rows_per_gpu": Ml, "optimizer": args.optimizer, "lr": lr,
                        "parallelism": (f"row-shard x{world}, library RCCL all-reduce of grad(Y) in {n_chunks} column chunks "
@@ -218,27 +224,29 @@ def main():
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / F32_MFMA_PEAK_TFLOPS, "traffic": None,
                          "kernel": "pmf_fused_kernel", "kernel_ms": k_ms, "launches": k_n,
-                         "hbm_stream_GBps": 4.0 * Ml * N / n_chunks / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0,
+                         "hbm_stream_GBps": dsz * Ml * N / n_chunks / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0,
                          # the co-bound.  Algorithmic HBM bytes of one epoch on this rank = D once
                          # + parameter / optimizer traffic (p, g, state read + p, state written) + the Y-reg beta
-                         "hbm_frac": ((4.0 * Ml * N + 4.0 * K * (Ml + N) * (7 if args.optimizer == "adam" else 5)
+                         "hbm_frac": ((dsz * Ml * N + 4.0 * K * (Ml + N) * (7 if args.optimizer == "adam" else 5)
                                        + 4.0 * K * N) / (dt / args.steps)) / 8.0e12,
                          "hbm_peak_GBps": 8000.0},
             "loss_first": losses[0], "loss_last": losses[-1],
         }
+        sb_name = "pmf_fused_sb_kernel" if K <= 64 else "pmf_fused_sb4_kernel"
         if split_main:
             # the split-bf16 kernel needs a quarter of the matrix cycles: what bounds it is the D stream
-            d_gbps = 4.0 * Ml * N / n_chunks / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
+            d_gbps = dsz * Ml * N / n_chunks / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
             out["roofline"].update({"bound": "hbm", "achieved": d_gbps, "peak": 8000.0, "unit": "GB/s", "frac": d_gbps / 8000.0,
-                                    "kernel": "pmf_fused_sb_kernel"})
+                                    "kernel": sb_name})
         # the other arithmetic on the same device data, initial factors and optimizer (pmf_set_precision)
-        took = (n_split2 > 0) if other == "bf16x3" else (n_split2 == 0)
-        out["other_precision"] = {
-            "precision": other, "kernel": "pmf_fused_sb_kernel" if other == "bf16x3" else "pmf_fused_kernel",
+        if have_other:
+          took = (n_split2 > 0) if other == "bf16x3" else (n_split2 == 0)
+          out["other_precision"] = {
+            "precision": other, "kernel": sb_name if other == "bf16x3" else "pmf_fused_kernel",
             "kernel_taken": took, "value": args.steps / dt2, "unit": "iters/s", "ms_per_step": dt2 / args.steps * 1e3,
             "kernel_ms": k_ms2, "launches": k_n2, "hbm_stream_GBps": 4.0 * Ml * N / n_chunks / (k_ms2 * 1e-3) / 1e9 if k_ms2 > 0 else 0.0,
             "loss_last": losses2[-1], "loss_last_rel_diff": abs(losses2[-1] - losses[-1]) / abs(losses[-1]),
-        }
+          }
         # HBM traffic of the dominant kernel: measured offline with rocprofv3 PMC passes (scripts/profile.sh) and
         # committed under profiles/; reported only when it was measured for exactly this workload
         try:

@@ -15,6 +15,7 @@ LIB_PATH = _HERE / "libpmf_hip.so"
 
 NOISE = {"normal": 0, "bernoulli": 1, "poisson": 2}
 OPT = {"adagrad": 0, "adam": 1}
+STORE = {"f32": 0, "bf16": 1}
 TERM = {0: "max_epochs", 1: "loss_increase", 2: "abs_tol", 3: "rel_tol", 4: "nonfinite"}
 PARAM = {"X": 0, "Y": 1, "logsigma": 2, "mu": 3, "logdelta": 4, "theta": 5}
 
@@ -163,14 +164,15 @@ class Context:
     def synchronize(self):
         self._chk(self.lib.pmf_synchronize(self._h))
 
-    def set_data(self, D):
+    def set_data(self, D, store="f32"):
+        """store = "bf16": the device copy of D is kept as bfloat16 (PMF_STORE_BF16; read by the split-bf16 data pass)."""
         D = _f32(D)
         self.M, self.N = D.shape
-        self._chk(self.lib.pmf_set_data(self._h, _fp(D), C.c_int64(self.M), C.c_int64(self.N), 0))
+        self._chk(self.lib.pmf_set_data(self._h, _fp(D), C.c_int64(self.M), C.c_int64(self.N), STORE[store]))
 
-    def set_data_device(self, ptr, M, N):
+    def set_data_device(self, ptr, M, N, store="f32"):
         self.M, self.N = int(M), int(N)
-        self._chk(self.lib.pmf_set_data_device(self._h, C.c_void_p(ptr), C.c_int64(M), C.c_int64(N), 0))
+        self._chk(self.lib.pmf_set_data_device(self._h, C.c_void_p(ptr), C.c_int64(M), C.c_int64(N), STORE[store]))
 
     def set_factors(self, X, Y):
         X, Y = _f32(X), _f32(Y)

@@ -59,7 +59,7 @@ struct ViewDesc {
 };
 
 struct FusedArgs {
-  const float *D;       // tile-major, see pmf_d_off; nRB row blocks x roundup(N,64)/32 column blocks
+  const void *D;        // tile-major f32 (pmf_d_off) or bf16 (pmf_d_off16); nRB row blocks x roundup(N,64)/32 column blocks
   const uint32_t *tflags;  // per 32x32 tile (same order as the tiles of D): 1 = every entry finite (k_tile_flags)
   int64_t nRB;
   const float *X;
@@ -192,6 +192,81 @@ struct SbSplitArgs {
   char *out;
 };
 
+// transposed LDS read of eight bf16 (two ds_read_b64_tr_b16)
+__device__ __forceinline__ bf16x8 pmf_sb_tr8(const char *p0, const char *p1) {
+  typedef s16x4 __attribute__((address_space(3))) * lds_p;
+  const s16x4 t0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(p0));
+  const s16x4 t1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(p1));
+  typedef short s16x8 __attribute__((ext_vector_type(8)));
+  const s16x8 t = __builtin_shufflevector(t0, t1, 0, 1, 2, 3, 4, 5, 6, 7);
+  return __builtin_bit_cast(bf16x8, t);
+}
+
+
+// ---- split-bf16 operands for 64 < K <= 128 (pmf_fused_sb4.hip.inc): 256-byte image rows whatever K
+__host__ __device__ __forceinline__ int pmf_sb4_off(int row, int ch) { return 256 * row + 16 * (ch ^ (((row & 3) << 2) | ((row >> 2) & 3))); }
+template <int KB>
+struct Sb4Cfg {
+  static constexpr int NW = 4, Kp = 32 * KB, SLAB = 32 * Kp;
+  static constexpr int IMG = 32 * 256;     // bytes of one [32 rows][128 k] bf16 image
+  static constexpr int XBLK = 5 * IMG;     // per 32 samples: hi, mid, lo row images + hi, mid transposed images
+  static constexpr int YBLK = 3 * IMG;     // per 32 features: hi, mid, lo row images
+  static constexpr size_t lds_bytes = (2 * 2 * IMG + IMG + NW * SLAB * 4 + 8 * PMF_BN * 4 + 16 + 8 * NW + 15) / 16 * 16;
+  static constexpr size_t lds_batch(int n_bv) { return PMF_BN * 16 * sizeof(float2) + (size_t)NW * n_bv * 32; }
+  static constexpr int max_bv = PMF_MAXV;
+};
+struct Sb4SplitArgs {
+  const float *src;
+  const float4 *colp;
+  int64_t n, nblk;
+  int32_t Ksrc, transposed;   // transposed: also write the two transposed images (X); block stride 5 images, else 3
+  char *out;
+};
+// ---- the data matrix tile in registers, f32 or bf16 storage
+// bf16 device layout of D (PMF_STORE_BF16): 32 x 32 tiles of 2 KiB in the same tile order as the f32 layout; inside a
+// tile 32-bit word q*256 + lane*4 + e holds accumulator registers 8q + 2e (low half) and 8q + 2e + 1 (high half) of
+// lane = h*32 + (i & 31): a wave streams its tile with two 1-KiB loads.
+__host__ __device__ __forceinline__ int64_t pmf_d_off16(int64_t i, int64_t j, int64_t nRB) {
+  const int il = (int)(i & 31), jl = (int)(j & 31);
+  const int h = (jl >> 2) & 1;
+  const int r = (jl & 3) + 4 * (jl >> 3);
+  return (((j >> 5) * nRB) + (i >> 5)) * 1024 + ((r >> 3) * 256 + (h * 32 + il) * 4 + ((r & 7) >> 1)) * 2 + (r & 1);
+}
+// DB: the data matrix is stored as bf16 (PMF_STORE_BF16): two 1-KiB wave loads per tile instead of four; the registers
+// keep the raw words until the epilogue converts them (a load's result must not be touched where it is issued).
+template <bool DB>
+struct PmfDTile;
+template <>
+struct PmfDTile<false> {
+  f32x16 v;
+  static constexpr int NCH = 4;
+  __device__ __forceinline__ float get(int r) const { return v[r]; }
+  __device__ __forceinline__ void load(const void *D, int64_t tile, int lane, int q) {
+    const float4 x = pmf_load_stream(reinterpret_cast<const float4 *>(reinterpret_cast<const float *>(D) + tile * 1024) + lane + 64 * q);
+    v[4 * q + 0] = x.x; v[4 * q + 1] = x.y; v[4 * q + 2] = x.z; v[4 * q + 3] = x.w;
+  }
+  __device__ __forceinline__ void touch() const { const f32x16 k = v; asm volatile("" ::"v"(k)); }
+};
+template <>
+struct PmfDTile<true> {
+  uint32_t w[8];   // word e of chunk q = registers 8q + 2e (low half) and 8q + 2e + 1 (high half)
+  static constexpr int NCH = 2;
+  __device__ __forceinline__ float get(int r) const {
+    const uint32_t x = w[r >> 1];
+    return __uint_as_float((r & 1) ? (x & 0xffff0000u) : (x << 16));
+  }
+  __device__ __forceinline__ void load(const void *D, int64_t tile, int lane, int q) {
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    const u32x4 x = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(reinterpret_cast<const uint16_t *>(D) + tile * 1024) + lane + 64 * q);
+    w[4 * q + 0] = x.x; w[4 * q + 1] = x.y; w[4 * q + 2] = x.z; w[4 * q + 3] = x.w;
+  }
+  __device__ __forceinline__ void touch() const {
+    const uint32_t a0 = w[0], a1 = w[1], a2 = w[2], a3 = w[3], a4 = w[4], a5 = w[5], a6 = w[6], a7 = w[7];
+    asm volatile("" ::"v"(a0), "v"(a1), "v"(a2), "v"(a3), "v"(a4), "v"(a5), "v"(a6), "v"(a7));
+  }
+};
+
+
 // ---- layer pass (pmf_layers.hip.inc)
 #define PMF_LS 2   // column tiles per unit (4 was measured: more per-tile state in registers, more spills, 19.6 vs 13.5 ms)
 
@@ -227,6 +302,11 @@ int pmf_launch_fused_exact_31(PmfDynLds *cache, hipStream_t stream, const FusedA
 int pmf_launch_fused_exact_41(PmfDynLds *cache, hipStream_t stream, const FusedArgs &a, int grid, bool batch, bool mixed);
 int pmf_launch_fused_sb_1(PmfDynLds *cache, hipStream_t stream, const FusedArgs &a, int grid, bool batch, bool mixed, bool want_gx, bool want_gy);
 int pmf_launch_fused_sb_2(PmfDynLds *cache, hipStream_t stream, const FusedArgs &a, int grid, bool batch, bool mixed, bool want_gx, bool want_gy);
+int pmf_launch_fused_sb_1_bf16(PmfDynLds *cache, hipStream_t stream, const FusedArgs &a, int grid, bool batch, bool mixed, bool want_gx, bool want_gy);
+int pmf_launch_fused_sb_2_bf16(PmfDynLds *cache, hipStream_t stream, const FusedArgs &a, int grid, bool batch, bool mixed, bool want_gx, bool want_gy);
+int pmf_launch_fused_sb4_4(PmfDynLds *cache, hipStream_t stream, const FusedArgs &a, int grid, bool batch, bool mixed, bool want_gx, bool want_gy);
+int pmf_launch_fused_sb4_4_bf16(PmfDynLds *cache, hipStream_t stream, const FusedArgs &a, int grid, bool batch, bool mixed, bool want_gx, bool want_gy);
+int pmf_launch_sb4_split(hipStream_t stream, const Sb4SplitArgs &a);
 int pmf_launch_sb_split_1(hipStream_t stream, const SbSplitArgs &a);
 int pmf_launch_sb_split_2(hipStream_t stream, const SbSplitArgs &a);
 int pmf_launch_layer_pass(PmfDynLds *cache, hipStream_t stream, int KB, int lnw, bool mixed, int grid, const LayerPassArgs &a);

@@ -82,7 +82,7 @@ struct pmf_ctx {
   int n_cu = 256;
   int64_t M = 0, N = 0;
   int K = 0, Kp = 0, KB = 0;
-  float *D = nullptr;  // tile-major copy of the data matrix (pmf_d_off), always library-owned
+  void *D = nullptr;   // tile-major copy of the data matrix, f32 (pmf_d_off) or bf16 (pmf_d_off16, `store`), always library-owned
   bool own_D = false;
   int64_t D_M = 0, D_Npad = 0, nRB = 0;
   uint32_t *tflags = nullptr;     // per 32x32 tile of D: 1 = all 1024 entries finite (fast epilogue path of the fused kernel)
@@ -323,11 +323,21 @@ __global__ void k_pad_copy(float *dst, const float *src, int Kp, int K, int64_t 
 }
 
 // column-major source block (rows 0..M-1, columns col0..col0+ncols-1, leading dimension M) -> tile-major D
-__global__ void k_tile_D(const float *src, int64_t M, int64_t col0, int64_t ncols, float *dst, int64_t nRB) {
+// (bf16 storage: round to nearest even, NaN stays NaN)
+__global__ void k_tile_D(const float *src, int64_t M, int64_t col0, int64_t ncols, void *dst, int64_t nRB, int bf16) {
   const int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   if (e >= M * ncols) return;
   const int64_t i = e % M, jl = e / M;
-  dst[pmf_d_off(i, col0 + jl, nRB)] = src[e];
+  if (bf16) reinterpret_cast<__bf16 *>(dst)[pmf_d_off16(i, col0 + jl, nRB)] = (__bf16)src[e];
+  else reinterpret_cast<float *>(dst)[pmf_d_off(i, col0 + jl, nRB)] = src[e];
+}
+__global__ void k_fill16(uint16_t *p, int64_t n, uint16_t v) {
+  for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) p[e] = v;
+}
+// one entry of the tile-major data matrix, whatever its storage type (the rarely-run scalar kernels)
+__device__ __forceinline__ float pmf_d_get(const void *D, int64_t i, int64_t j, int64_t nRB, int bf16) {
+  if (bf16) return __uint_as_float((uint32_t)reinterpret_cast<const uint16_t *>(D)[pmf_d_off16(i, j, nRB)] << 16);
+  return reinterpret_cast<const float *>(D)[pmf_d_off(i, j, nRB)];
 }
 
 __device__ __forceinline__ double block_reduce_sum(double v, double *sh) {
@@ -433,7 +443,9 @@ __global__ __launch_bounds__(256) void k_loss_reduce(const double *data_partial,
 //   logsigma_bar[j]   = sigma_j * sum_i g * delta           (layers.jl:40-41; Q1: omits the input factor)
 // ------------------------------------------------------------------------------------------------
 struct LayerGradArgs {
-  const float *D, *X, *Y;
+  const void *D;
+  int d_bf16;
+  const float *X, *Y;
   const float4 *colp;
   const int32_t *bor;
   const float2 *btab;
@@ -512,7 +524,7 @@ __global__ __launch_bounds__(64) void k_layer_grad(const LayerGradArgs a) {
           th = dt.y;
         }
       }
-      const float yv = a.D[pmf_d_off(i, jc, a.nRB)];
+      const float yv = pmf_d_get(a.D, i, jc, a.nRB, a.d_bf16);
       const float z1 = acc * cp.x;
       const float z = fmaf(z1, dl, cp.y + th);
       float l, g;
@@ -564,7 +576,9 @@ __global__ __launch_bounds__(64) void k_layer_grad(const LayerGradArgs a) {
 // Called a handful of times per fit, not per epoch.
 // ------------------------------------------------------------------------------------------------
 struct StatsArgs {
-  const float *D, *X, *Y;
+  const void *D;
+  int d_bf16;
+  const float *X, *Y;
   const float4 *colp;
   const int32_t *bor;
   const float2 *btab;
@@ -643,7 +657,7 @@ __global__ __launch_bounds__(64) void k_stats(const StatsArgs a) {
           th = dt.y;
         }
       }
-      const float yv = a.D[pmf_d_off(i, jc, a.nRB)];
+      const float yv = pmf_d_get(a.D, i, jc, a.nRB, a.d_bf16);
       if (!(fabsf(yv) <= 3.402823466e38f)) continue;
       const float z = fmaf(acc * cp.x, dl, cp.y + th);
       float pred, g;
@@ -681,7 +695,8 @@ struct ForwardArgs {
   const int32_t *bor;
   const float2 *btab;
   float *Z;
-  int64_t M, N, nRB;   // nRB > 0: write Z in the tile-major data layout (synthetic data), else column-major
+  int64_t M, N, nRB;   // nRB > 0: write Z in the tile-major data layout (synthetic data; z_bf16: as bf16), else column-major
+  int z_bf16;
   int Kp, K;
   int synth;
   uint64_t seed;
@@ -733,7 +748,8 @@ __global__ __launch_bounds__(256) void k_forward(const ForwardArgs a) {
     const float u3 = (r2 >> 40) * (1.0f / 16777216.0f);
     if (u3 < a.frac_nan) z = __int_as_float(0x7fc00000);
   }
-  a.Z[a.nRB > 0 ? pmf_d_off(i, j, a.nRB) : j * a.M + i] = z;
+  if (a.nRB > 0 && a.z_bf16) reinterpret_cast<__bf16 *>(a.Z)[pmf_d_off16(i, j, a.nRB)] = (__bf16)z;
+  else a.Z[a.nRB > 0 ? pmf_d_off(i, j, a.nRB) : j * a.M + i] = z;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -818,7 +834,8 @@ extern "C" int pmf_destroy(pmf_ctx *c) {
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
   for (auto &b : c->P) param_free(b);
-  if (c->own_D) dev_free(&c->D);
+  if (c->D) (void)hipFree(c->D);
+  c->D = nullptr;
   dev_free(&c->tflags);
   dev_free(&c->bor); dev_free(&c->btab); dev_free(&c->btd); c->btd_cap = 0; c->btd_ok = false; dev_free(&c->LG); c->LG_cap = 0; dev_free(&c->d_views); c->views_dirty = true; dev_free(&c->d_val_view);
   dev_free(&c->colmeta); dev_free(&c->colw); dev_free(&c->colp);
@@ -899,20 +916,24 @@ static int data_shape_changed(pmf_ctx *c, int64_t M, int64_t N) {
 
 // The device copy of D is tile-major (pmf_d_off): nRB = ceil(M/32) row blocks x ceil(N/64)*2 column blocks of
 // 32 x 32 floats, NaN-filled outside the matrix.
-static int alloc_tiled_D(pmf_ctx *c, int64_t M, int64_t N) {
+static int alloc_tiled_D(pmf_ctx *c, int64_t M, int64_t N, int store) {
   const int64_t Npad = (N + PMF_DPAD - 1) / PMF_DPAD * PMF_DPAD;
   const int64_t nRB = (M + 31) / 32;
   const int64_t nfl = nRB * 32 * Npad;
-  if (!(c->D && c->D_M == M && c->D_Npad == Npad)) {
-    dev_free(&c->D);
-    HIPCHK(hipMalloc((void **)&c->D, sizeof(float) * (size_t)nfl));
+  const size_t esz = store == PMF_STORE_BF16 ? 2 : 4;
+  if (!(c->D && c->D_M == M && c->D_Npad == Npad && c->store == store)) {
+    if (c->D) (void)hipFree(c->D);
+    c->D = nullptr;
+    HIPCHK(hipMalloc(&c->D, esz * (size_t)nfl));
     c->own_D = true;
     c->D_M = M;
     c->D_Npad = Npad;
     c->nRB = nRB;
   }
   c->tflags_valid = false;
-  k_fill<<<(int)std::min<int64_t>(nblocks(nfl, 256), 65536), 256, 0, c->stream>>>(c->D, nfl, __builtin_nanf(""));
+  c->store = store;
+  if (store == PMF_STORE_BF16) k_fill16<<<(int)std::min<int64_t>(nblocks(nfl, 256), 65536), 256, 0, c->stream>>>((uint16_t *)c->D, nfl, (uint16_t)0x7fc0);
+  else k_fill<<<(int)std::min<int64_t>(nblocks(nfl, 256), 65536), 256, 0, c->stream>>>((float *)c->D, nfl, __builtin_nanf(""));
   HIPCHK(hipGetLastError());
   return 0;
 }
@@ -920,7 +941,7 @@ static int alloc_tiled_D(pmf_ctx *c, int64_t M, int64_t N) {
 static int tile_from_device(pmf_ctx *c, const float *src, int64_t col0, int64_t ncols) {
   const int64_t n = c->M * ncols;
   c->tflags_valid = false;
-  k_tile_D<<<nblocks(n, 256), 256, 0, c->stream>>>(src, c->M, col0, ncols, c->D, c->nRB);
+  k_tile_D<<<nblocks(n, 256), 256, 0, c->stream>>>(src, c->M, col0, ncols, c->D, c->nRB, c->store == PMF_STORE_BF16);
   HIPCHK(hipGetLastError());
   return 0;
 }
@@ -928,9 +949,9 @@ static int tile_from_device(pmf_ctx *c, const float *src, int64_t col0, int64_t 
 extern "C" int pmf_set_data(pmf_ctx *c, const float *D, int64_t M, int64_t N, int store) {
   PMFCHK(ctx_bind(c));
   if (!D) return pmf_fail("null data pointer");
-  if (store != PMF_STORE_F32) return pmf_fail("only PMF_STORE_F32 is implemented");
+  if (store != PMF_STORE_F32 && store != PMF_STORE_BF16) return pmf_fail("unknown storage type %d", store);
   PMFCHK(data_shape_changed(c, M, N));
-  PMFCHK(alloc_tiled_D(c, M, N));
+  PMFCHK(alloc_tiled_D(c, M, N, store));
   // upload in column chunks of <= 256 MiB through a staging buffer, tiling each chunk on the device
   const int64_t chunk = std::max<int64_t>(1, std::min<int64_t>(N, (64ll << 20) / std::max<int64_t>(M, 1)));
   PMFCHK(ensure_scratch(c, sizeof(float) * (size_t)(M * chunk)));
@@ -940,17 +961,15 @@ extern "C" int pmf_set_data(pmf_ctx *c, const float *D, int64_t M, int64_t N, in
     PMFCHK(tile_from_device(c, (const float *)c->scratch, c0, nc));
     HIPCHK(hipStreamSynchronize(c->stream));
   }
-  c->store = store;
   return 0;
 }
 extern "C" int pmf_set_data_device(pmf_ctx *c, const void *D, int64_t M, int64_t N, int store) {
   PMFCHK(ctx_bind(c));
-  if (store != PMF_STORE_F32) return pmf_fail("only PMF_STORE_F32 is implemented");
+  if (store != PMF_STORE_F32 && store != PMF_STORE_BF16) return pmf_fail("unknown storage type %d", store);
   PMFCHK(data_shape_changed(c, M, N));
-  PMFCHK(alloc_tiled_D(c, M, N));      // D == NULL: left all-NaN for pmf_synth_data
+  PMFCHK(alloc_tiled_D(c, M, N, store));      // D == NULL: left all-NaN for pmf_synth_data
   if (D) PMFCHK(tile_from_device(c, (const float *)D, 0, N));
   HIPCHK(hipStreamSynchronize(c->stream));
-  c->store = store;
   return 0;
 }
 
@@ -1364,12 +1383,17 @@ static int prepare(pmf_ctx *c) {
 
 // One workgroup per 32x32 tile of the tile-major D: flag = 1 iff all 1024 entries are finite.  The fused kernel takes
 // its packed-math epilogue (no per-entry missing-value mask) on flagged tiles.  Recomputed lazily whenever D changes.
-__global__ void k_tile_flags(const float *__restrict__ D, int64_t ntiles, uint32_t *__restrict__ flags) {
+__global__ void k_tile_flags(const void *__restrict__ D, int64_t ntiles, uint32_t *__restrict__ flags, int bf16) {
   const int64_t t = blockIdx.x;
   if (t >= ntiles) return;
-  const float4 v = reinterpret_cast<const float4 *>(D + t * 1024)[threadIdx.x];   // 256 threads x 16 B
-  const bool ok = fabsf(v.x) <= 3.402823466e38f && fabsf(v.y) <= 3.402823466e38f && fabsf(v.z) <= 3.402823466e38f &&
-                  fabsf(v.w) <= 3.402823466e38f;
+  bool ok;
+  if (bf16) {   // 256 threads x 8 B; finite <=> the exponent field is not all ones
+    const uint2 v = reinterpret_cast<const uint2 *>(reinterpret_cast<const uint16_t *>(D) + t * 1024)[threadIdx.x];
+    ok = (v.x & 0x7f80u) != 0x7f80u && (v.x & 0x7f800000u) != 0x7f800000u && (v.y & 0x7f80u) != 0x7f80u && (v.y & 0x7f800000u) != 0x7f800000u;
+  } else {
+    const float4 v = reinterpret_cast<const float4 *>(reinterpret_cast<const float *>(D) + t * 1024)[threadIdx.x];   // 256 threads x 16 B
+    ok = fabsf(v.x) <= 3.402823466e38f && fabsf(v.y) <= 3.402823466e38f && fabsf(v.z) <= 3.402823466e38f && fabsf(v.w) <= 3.402823466e38f;
+  }
   const int all_ok = __syncthreads_and(ok ? 1 : 0);
   if (threadIdx.x == 0) flags[t] = all_ok ? 1u : 0u;
 }
@@ -1382,7 +1406,7 @@ static int ensure_tile_flags(pmf_ctx *c) {
     c->tflags_cap = ntiles;
   }
   if (ntiles > 0x7fffffff) return pmf_fail("too many tiles");
-  k_tile_flags<<<(unsigned)ntiles, 256, 0, c->stream>>>(c->D, ntiles, c->tflags);
+  k_tile_flags<<<(unsigned)ntiles, 256, 0, c->stream>>>(c->D, ntiles, c->tflags, c->store == PMF_STORE_BF16);
   HIPCHK(hipGetLastError());
   c->tflags_valid = true;
   return 0;
@@ -1460,7 +1484,7 @@ __global__ __launch_bounds__(256) void k_gx_reduce(const float *__restrict__ par
 // Geometry of one fused data pass: kernel variant, row panels, column chunks.
 struct FusedGeom {
   int NW = 8, RBW = 1, BM = 256, grid_max = 256, S = 1;
-  bool sb = false;
+  bool sb = false;    // split-bf16 products: pmf_fused_sb_kernel (K <= 64) or pmf_fused_sb4_kernel (64 < K <= 128)
   int64_t n_rp = 0, n_ct_all = 0;
   int64_t ct0[PMF_MAX_CHUNKS], nct[PMF_MAX_CHUNKS];
 };
@@ -1597,8 +1621,10 @@ static FusedGeom fused_geometry(pmf_ctx *c, bool want_gx, bool want_gy, bool all
   if (rbwenv && c->KB == 1 && atoi(rbwenv) == 1) g.RBW = 1;
   // split-bf16 products (opt-in, pmf_set_precision): K <= 64; one row block per wave
   // (batch layers: through the dense LDS table only, i.e. <= 15 batches per view, and as many views as LDS has room for)
-  const bool sb_batch_ok = c->n_bv == 0 || (c->btd_ok && c->n_bv <= (c->KB == 1 ? SbCfg<1>::max_bv : SbCfg<2>::max_bv));
-  g.sb = c->precision == PMF_PREC_BF16X3 && c->KB <= 2 && sb_batch_ok && (want_gx || want_gy) && !getenv("PMF_DEBUG_FLAGS");
+  const int sb_max_bv = c->KB == 1 ? SbCfg<1>::max_bv : (c->KB == 2 ? SbCfg<2>::max_bv : Sb4Cfg<4>::max_bv);
+  const bool sb_batch_ok = c->n_bv == 0 || (c->btd_ok && c->n_bv <= sb_max_bv);
+  // (K in 65..96 keeps three K blocks in the parameter buffers: no split variant is built for that stride)
+  g.sb = c->precision == PMF_PREC_BF16X3 && c->KB != 3 && sb_batch_ok && (want_gx || want_gy) && !getenv("PMF_DEBUG_FLAGS");
   if (g.sb) g.RBW = 1;
   g.BM = 32 * g.NW * g.RBW;
   g.n_rp = (c->M + g.BM - 1) / g.BM;
@@ -1700,8 +1726,9 @@ static int prepare_fused_pass(pmf_ctx *c, const FusedGeom &g, bool want_gx, bool
   }
   PMFCHK(ensure_tile_flags(c));
   if (g.sb) {
-    const size_t blk = c->KB == 1 ? SbCfg<1>::BLK : SbCfg<2>::BLK;
-    const size_t xb = (size_t)c->nRB * blk, yb = (size_t)g.n_ct_all * blk;
+    const size_t xblk = c->KB == 1 ? SbCfg<1>::BLK : (c->KB == 2 ? SbCfg<2>::BLK : Sb4Cfg<4>::XBLK);
+    const size_t yblk = c->KB == 1 ? SbCfg<1>::BLK : (c->KB == 2 ? SbCfg<2>::BLK : Sb4Cfg<4>::YBLK);
+    const size_t xb = (size_t)c->nRB * xblk, yb = (size_t)g.n_ct_all * yblk;
     if (xb > c->xsb_cap) { dev_free(&c->xsb); c->xsb_cap = 0; PMFCHK(dev_alloc(&c->xsb, xb, false)); c->xsb_cap = xb; }
     if (yb > c->ysb_cap) { dev_free(&c->ysb); c->ysb_cap = 0; PMFCHK(dev_alloc(&c->ysb, yb, false)); c->ysb_cap = yb; }
   }
@@ -1711,10 +1738,19 @@ static int prepare_fused_pass(pmf_ctx *c, const FusedGeom &g, bool want_gx, bool
 // split-bf16 operand images (k_sb_split): X once per pass, sigma*Y per chunk (its columns only: the Y step of a later
 // chunk of the previous epoch may not have run yet when an earlier chunk is launched, pmf_fit)
 static int sb_split_x(pmf_ctx *c) {
+  if (c->KB > 2) {
+    Sb4SplitArgs s4 = {c->P[0].p, nullptr, c->M, c->nRB, c->Kp, 1, c->xsb};
+    return pmf_launch_sb4_split(c->stream, s4);
+  }
   SbSplitArgs sx = {c->P[0].p, nullptr, c->M, c->nRB, c->xsb};
   return c->KB == 1 ? pmf_launch_sb_split_1(c->stream, sx) : pmf_launch_sb_split_2(c->stream, sx);
 }
 static int sb_split_y(pmf_ctx *c, int64_t ct0, int64_t nct) {
+  if (c->KB > 2) {
+    const int64_t c0 = ct0 * 32;
+    Sb4SplitArgs s4 = {c->P[1].p + c0 * c->Kp, c->colp + c0, c->N - c0, nct, c->Kp, 0, c->ysb + (size_t)ct0 * Sb4Cfg<4>::YBLK};
+    return pmf_launch_sb4_split(c->stream, s4);
+  }
   const size_t blk = c->KB == 1 ? SbCfg<1>::BLK : SbCfg<2>::BLK;
   const int64_t col0 = ct0 * 32;
   SbSplitArgs sy = {c->P[1].p + col0 * c->Kp, c->colp + col0, c->N - col0, nct, c->ysb + (size_t)ct0 * blk};
@@ -1780,9 +1816,16 @@ static int launch_fused_chunk(pmf_ctx *c, const FusedGeom &g, int s, bool want_g
   HIPCHK(hipEventRecord(ev.first, c->stream));
   int rc = 0;
   if (g.sb) {
-    rc = c->KB == 1 ? pmf_launch_fused_sb_1(&c->dyn_lds, c->stream, a, grid, batch, c->mixed, want_gx, want_gy)
-                    : pmf_launch_fused_sb_2(&c->dyn_lds, c->stream, a, grid, batch, c->mixed, want_gx, want_gy);
+    const bool d16 = c->store == PMF_STORE_BF16;
+    typedef int (*sb_fn)(PmfDynLds *, hipStream_t, const FusedArgs &, int, bool, bool, bool, bool);
+    const sb_fn fn = c->KB == 1 ? (d16 ? pmf_launch_fused_sb_1_bf16 : pmf_launch_fused_sb_1)
+                   : c->KB == 2 ? (d16 ? pmf_launch_fused_sb_2_bf16 : pmf_launch_fused_sb_2)
+                                : (d16 ? pmf_launch_fused_sb4_4_bf16 : pmf_launch_fused_sb4_4);
+    rc = fn(&c->dyn_lds, c->stream, a, grid, batch, c->mixed, want_gx, want_gy);
     c->sb_launches += 1;
+  } else if (c->store == PMF_STORE_BF16) {
+    return pmf_fail("a data matrix stored as bf16 (PMF_STORE_BF16) is read by the split-bf16 data pass only: "
+                    "pmf_set_precision(ctx, PMF_PREC_BF16X3), K <= 64 or 96 < K <= 128, at most 15 batches per view");
   } else
   switch (c->KB * 10 + g.RBW) {
     case 11: rc = pmf_launch_fused_exact_11(&c->dyn_lds, c->stream, a, grid, batch, c->mixed); break;
@@ -1819,7 +1862,7 @@ static int launch_fused(pmf_ctx *c, bool want_gx, bool want_gy) {
 static int launch_layer_grad(pmf_ctx *c, const pmf_fit_opts *o, bool with_loss) {
   LayerGradArgs a;
   memset(&a, 0, sizeof(a));
-  a.D = c->D; a.X = c->P[0].p; a.Y = c->P[1].p; a.colp = c->colp; a.bor = c->bor; a.btab = c->btab;
+  a.D = c->D; a.d_bf16 = c->store == PMF_STORE_BF16; a.X = c->P[0].p; a.Y = c->P[1].p; a.colp = c->colp; a.bor = c->bor; a.btab = c->btab;
   const int fl = o->frozen_layers;
   a.g_logsigma = (fl & 1) ? nullptr : c->P[2].g;
   a.g_logdelta = ((fl & 2) || c->n_bv == 0) ? nullptr : c->P[4].g;
@@ -1869,7 +1912,7 @@ static int launch_layer_grad(pmf_ctx *c, const pmf_fit_opts *o, bool with_loss) 
 static bool layer_pass_eligible(pmf_ctx *c) {
   const char *e = getenv("PMF_LAYER_OLD");
   if (e && atoi(e) == 1) return false;
-  return c->KB <= 4 && (c->n_bv == 0 || c->btd_ok);
+  return c->KB <= 4 && (c->n_bv == 0 || c->btd_ok) && c->store == PMF_STORE_F32;   // (bf16 storage: the scalar kernel reads it)
 }
 static int launch_layer_pass(pmf_ctx *c, const pmf_fit_opts *o, bool with_loss) {
   const char *lnwenv = getenv("PMF_LAYER_NW");
@@ -1892,7 +1935,7 @@ static int launch_layer_pass(pmf_ctx *c, const pmf_fit_opts *o, bool with_loss) 
   }
   LayerPassArgs a;
   memset(&a, 0, sizeof(a));
-  a.D = c->D; a.nRB = c->nRB; a.X = c->P[0].p; a.Y = c->P[1].p; a.colp = c->colp; a.bor = c->bor;
+  a.D = (const float *)c->D; a.nRB = c->nRB; a.X = c->P[0].p; a.Y = c->P[1].p; a.colp = c->colp; a.bor = c->bor;
   a.btd = c->n_bv > 0 ? c->btd : nullptr; a.LG = c->LG; a.loss_partial = with_loss ? c->loss_partial : nullptr;
   a.M = c->M; a.N = c->N; a.n_bv = c->n_bv; a.n_ct = (int)n_ct; a.n_rp = (int)n_rp; a.n_seg = (int)n_seg; a.R = (int)R;
   PMFCHK(pmf_launch_layer_pass(&c->dyn_lds, c->stream, c->KB, lnw, c->mixed, grid, a));
@@ -2271,6 +2314,9 @@ extern "C" int pmf_fit(pmf_ctx *c, const pmf_fit_opts *o, pmf_fit_result *res) {
   const bool ux = o->update_X != 0, uy = o->update_Y != 0, ul = o->update_col_layers != 0;
   const bool fused = ux || uy || !ul;
   const bool cm = comm_active(c);
+  // (the first epoch is opened before the geometry is chosen: prepare() decides whether the dense batch table exists,
+  //  which decides the kernel variant and with it the row-panel height)
+  if (o->epoch <= o->max_epochs) PMFCHK(epoch_open(c, o));
   FusedGeom g;
   if (fused) g = fused_geometry(c, ux, uy, /*allow_chunks=*/!ul);
   const int S = fused ? g.S : 1;
@@ -2316,7 +2362,6 @@ extern "C" int pmf_fit(pmf_ctx *c, const pmf_fit_opts *o, pmf_fit_result *res) {
 
   bool in_flight = false;   // a data pass whose epoch has not been finished is enqueued
   if (o->epoch <= o->max_epochs) {
-    PMFCHK(epoch_open(c, o));
     if (fused) PMFCHK(prepare_fused_pass(c, g, ux, uy));
     for (int s = 0; s < S; ++s) PMFCHK(pass_chunk(s));
     in_flight = true;
@@ -2469,6 +2514,7 @@ static int run_forward(pmf_ctx *c, float *Zdev, int synth, uint64_t seed, float 
   ForwardArgs a;
   memset(&a, 0, sizeof(a));
   a.X = c->P[0].p; a.Y = c->P[1].p; a.colp = c->colp; a.bor = c->bor; a.btab = c->btab; a.Z = Zdev;
+  a.z_bf16 = nRB > 0 && c->store == PMF_STORE_BF16;
   a.M = c->M; a.N = c->N; a.nRB = nRB; a.Kp = c->Kp; a.K = c->K; a.synth = synth; a.seed = seed; a.noise = noise; a.frac_nan = frac_nan;
   for (int v = 0; v < c->n_bv; ++v) a.views[v] = c->views[v];
   if ((c->M + 255) / 256 > 65535) return pmf_fail("M too large for the forward kernel grid");
@@ -2497,7 +2543,7 @@ extern "C" int pmf_synth_data(pmf_ctx *c, uint64_t seed, float noise, float frac
   PMFCHK(ctx_bind(c));
   if (!c->D) return pmf_fail("data buffer not allocated (pmf_set_data_device(ctx, NULL, M, N, store))");
   c->tflags_valid = false;
-  PMFCHK(run_forward(c, c->D, 1, seed, noise, frac_nan, c->nRB));
+  PMFCHK(run_forward(c, (float *)c->D, 1, seed, noise, frac_nan, c->nRB));
   HIPCHK(hipStreamSynchronize(c->stream));
   return 0;
 }
@@ -2514,7 +2560,7 @@ extern "C" int pmf_stats(pmf_ctx *c, int use_factors, float *col_n, float *col_s
   HIPCHK(hipMemsetAsync(buf, 0, sizeof(float) * nfl, c->stream));
   StatsArgs a;
   memset(&a, 0, sizeof(a));
-  a.D = c->D; a.X = c->P[0].p; a.Y = c->P[1].p; a.colp = c->colp; a.bor = c->bor; a.btab = c->btab;
+  a.D = c->D; a.d_bf16 = c->store == PMF_STORE_BF16; a.X = c->P[0].p; a.Y = c->P[1].p; a.colp = c->colp; a.bor = c->bor; a.btab = c->btab;
   a.col_n = buf; a.col_sum = buf + c->N; a.col_sumsq = buf + 2 * c->N; a.col_sqerr = buf + 3 * c->N; a.col_ssqg = buf + 4 * c->N;
   a.b_n = nbt ? buf + 5 * c->N : nullptr;
   a.b_sqerr = nbt ? buf + 5 * c->N + nbt : nullptr;

@@ -121,10 +121,10 @@ def test_split_bf16_agrees_with_exact_kernel_at_config_size(sctx):
 
 
 def test_split_bf16_falls_back_to_exact_kernel_outside_its_scope(sctx):
-    """K > 64 and views with more than 15 batches (no dense LDS batch table) have no split-bf16 variant: they must run the
-    exact kernel (and say so through the launch counter), not fail."""
+    """64 < K <= 96 (three K blocks in the parameter buffers) and views with more than 15 batches (no dense LDS batch
+    table) have no split-bf16 variant: they must run the exact kernel (and say so through the launch counter), not fail."""
     ctx, n0 = sctx
-    for case in (dict(M=200, N=150, K=100),
+    for case in (dict(M=200, N=150, K=90),
                  dict(M=300, N=100, K=16, n_views=2, batch_views=2, n_batches=20, nan_frac=0.05, col_params=True)):
         p = make_problem(seed=11, **case)
         to_context(p, ctx)
@@ -164,3 +164,130 @@ def test_split_bf16_headline_size_properties(sctx):
     ctx, n0 = sctx
     exact_tests.test_headline_size_loss_and_gradient_consistency(ctx)
     assert ctx.get_precision()[1] == n0 + 4, "the split-bf16 kernel was not launched"
+
+
+# ---- 96 < K <= 128: pmf_fused_sb4_kernel (four waves, X operands in registers; csrc/pmf_fused_sb4.hip.inc) -------------
+CASES4 = {
+    "k100": dict(M=200, N=150, K=100, yreg="group", xreg="l2", col_params=True),
+    "k128_nan": dict(M=140, N=65, K=128, nan_frac=0.05, col_params=True),
+    "k128_ragged": dict(M=777, N=333, K=128, yreg="fsard", xreg="l2", nan_frac=0.1, weights=True, col_params=True, scale=0.4),
+    "k128_mixed": dict(M=600, N=420, K=128, bernoulli_frac=0.25, poisson_frac=0.15, n_views=3, nan_frac=0.08, weights=True,
+                       col_params=True, scale=0.3),
+    "k112_batch": dict(M=420, N=260, K=112, bernoulli_frac=0.2, n_views=2, batch_views=2, n_batches=8, nan_frac=0.1,
+                       weights=True, col_params=True, scale=0.4),
+    # several row panels per workgroup and several column segments: private-slab read-modify-write, many gX slots
+    "k128_many_panels": dict(M=40000, N=600, K=128, xreg="l2", weights=True, col_params=True, scale=0.3),
+    "k128_one_panel_many_cols": dict(M=33, N=1500, K=128, nan_frac=0.02, scale=0.4),
+}
+
+
+@pytest.mark.parametrize("name", list(CASES4))
+def test_split_bf16_k128_loss_and_gradients_match_oracle(sctx, name):
+    ctx, n0 = sctx
+    p = make_problem(seed=11, **CASES4[name])
+    to_context(p, ctx)
+    loss, g = grads_of(ctx, p, update_X=True, update_Y=True)
+    assert ctx.get_precision() == ("bf16x3", n0 + 1), "the split-bf16 kernel was not launched"
+    m = to_oracle(p)
+    m.m.n_xreg = 0
+    m.m.n_yreg = 0
+    _, gd = m.loss_and_grads(update_X=True, update_Y=True)
+    assert abs(loss - gd["data_loss"]) <= LOSS_RTOL * abs(gd["data_loss"]) + 1e-6, (loss, gd["data_loss"])
+    assert rel_err(g["X"], gd["X"]) <= GRAD_TOL, rel_err(g["X"], gd["X"])
+    assert rel_err(g["Y"], gd["Y"]) <= GRAD_TOL, rel_err(g["Y"], gd["Y"])
+
+
+@pytest.mark.parametrize("which", ["X", "Y"])
+@pytest.mark.parametrize("name", ["k128_ragged", "k112_batch"])
+def test_split_bf16_k128_single_factor_gradient_matches_oracle(sctx, name, which):
+    ctx, n0 = sctx
+    p = make_problem(seed=13, **CASES4[name])
+    to_context(p, ctx)
+    flags = dict(update_X=which == "X", update_Y=which == "Y")
+    loss, g = grads_of(ctx, p, **flags)
+    assert ctx.get_precision()[1] == n0 + 1
+    m = to_oracle(p)
+    m.m.n_xreg = 0
+    m.m.n_yreg = 0
+    _, go = m.loss_and_grads(**flags)
+    assert abs(loss - go["data_loss"]) <= LOSS_RTOL * abs(go["data_loss"]) + 1e-6
+    assert rel_err(g[which], go[which]) <= GRAD_TOL, rel_err(g[which], go[which])
+
+
+@pytest.mark.parametrize("opt", ["adagrad", "adam"])
+def test_split_bf16_k128_fit_trajectory_matches_oracle(sctx, opt):
+    ctx, n0 = sctx
+    p = make_problem(seed=13, random_init=True, **CASES4["k128_ragged"])
+    lr = 0.05 if opt == "adagrad" else 0.01
+    to_context(p, ctx)
+    ctx.set_optimizer(opt, lr=lr)
+    r = ctx.fit(update_X=True, update_Y=True, max_epochs=10, abs_tol=0, rel_tol=0)
+    assert ctx.get_precision()[1] == n0 + 10
+    m = to_oracle(p)
+    ro = m.fit(update_X=True, update_Y=True, opt=opt, lr=lr, max_epochs=10, abs_tol=0, rel_tol=0)
+    assert r["term_code"] == ro["term_code"] and r["epochs"] == ro["epochs"]
+    np.testing.assert_allclose(r["loss"], ro["loss"], rtol=5e-5)
+    X, Y = ctx.get_factors()
+    # AdaGrad's first steps are +-lr sign(g): on near-zero gradients the three-term gradient products' 4e-6 (of 128-term
+    # dot products) becomes an O(lr) difference in a few entries; the max-norm tolerance is widened for it, the loss trace
+    # above is not
+    tol = 8 * FIT_TOL if opt == "adagrad" else 2 * FIT_TOL
+    assert rel_err(X, m.X) <= tol, rel_err(X, m.X)
+    assert rel_err(Y, m.Y) <= tol, rel_err(Y, m.Y)
+
+
+# ---- the data matrix stored as bf16 (PMF_STORE_BF16; BASELINE configs[4] "D stored bf16") ------------------------------
+def bf16_round(D):
+    """float32 -> nearest bfloat16 (ties to even) -> float32, NaN kept: what k_tile_D's cast does on the device."""
+    u = np.ascontiguousarray(D, dtype=np.float32).view(np.uint32).astype(np.uint64)
+    r = ((u + 0x7FFF + ((u >> 16) & 1)) >> 16) << 16
+    out = r.astype(np.uint32).view(np.float32).reshape(D.shape)
+    return np.where(np.isnan(D), np.float32(np.nan), out).astype(np.float32)
+
+
+@pytest.mark.parametrize("name", ["ragged_k64_nan", "mixed_k48", "ragged_k32", "mixed_batch_nan_k64", "k128_ragged", "k112_batch",
+                                  "k128_many_panels"])
+def test_bf16_stored_data_matches_oracle_on_the_rounded_matrix(sctx, name):
+    """Tolerance of bf16 storage: NONE beyond the rounding of D itself -- fed the same bf16-rounded matrix, the oracle must
+    agree at the usual f32 tolerances (D enters the loss only through z - y and y z)."""
+    ctx, n0 = sctx
+    p = make_problem(seed=17, **(CASES[name] if name in CASES else CASES4[name]))
+    p["D"] = np.asfortranarray(bf16_round(p["D"]))
+    to_context(p, ctx)
+    ctx.set_data(p["D"], store="bf16")
+    loss, g = grads_of(ctx, p, update_X=True, update_Y=True)
+    assert ctx.get_precision()[1] == n0 + 1
+    m = to_oracle(p)
+    m.m.n_xreg = 0
+    m.m.n_yreg = 0
+    _, gd = m.loss_and_grads(update_X=True, update_Y=True)
+    assert abs(loss - gd["data_loss"]) <= LOSS_RTOL * abs(gd["data_loss"]) + 1e-6, (loss, gd["data_loss"])
+    assert rel_err(g["X"], gd["X"]) <= GRAD_TOL, rel_err(g["X"], gd["X"])
+    assert rel_err(g["Y"], gd["Y"]) <= GRAD_TOL, rel_err(g["Y"], gd["Y"])
+    # the unrounded matrix through the same call gives the same device bytes (the library rounds to nearest even)
+    st = ctx.stats(use_factors=True)
+    so = m.stats(use_factors=True)
+    np.testing.assert_array_equal(st["n"], so["n"].astype(np.float32))
+    assert rel_err(st["sqerr"], so["sqerr"]) <= 1e-4
+
+
+def test_bf16_stored_data_fit_and_layers(sctx):
+    """A fit on bf16-stored data (X, Y through the split kernel; the theta stage through the scalar layer kernel, which
+    reads either storage type) against the oracle on the rounded matrix."""
+    ctx, n0 = sctx
+    p = make_problem(seed=19, random_init=True, layer_regs=True, **CASES["mixed_batch_nan_k64"])
+    p["D"] = np.asfortranarray(bf16_round(p["D"]))
+    to_context(p, ctx)
+    ctx.set_data(p["D"], store="bf16")
+    ctx.set_optimizer("adagrad", lr=0.05)
+    r = ctx.fit(update_X=True, update_Y=True, max_epochs=6, abs_tol=0, rel_tol=0)
+    m = to_oracle(p)
+    ro = m.fit(update_X=True, update_Y=True, lr=0.05, max_epochs=6, abs_tol=0, rel_tol=0)
+    np.testing.assert_allclose(r["loss"], ro["loss"], rtol=5e-5)
+    kw = dict(update_col_layers=True, frozen_layers=0b0111, max_epochs=4, abs_tol=0, rel_tol=0)
+    ctx.set_optimizer("adagrad", lr=1.0)
+    m.reset_optimizer()
+    r2 = ctx.fit(**kw)
+    ro2 = m.fit(lr=1.0, **kw)
+    np.testing.assert_allclose(r2["loss"], ro2["loss"], rtol=5e-5)
+    ctx.set_data(p["D"])            # back to f32 storage for the tests that follow
