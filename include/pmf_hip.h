@@ -251,6 +251,19 @@ int pmf_forward(pmf_ctx *ctx, float *Z_host);
 int pmf_stats(pmf_ctx *ctx, int use_factors, float *col_n, float *col_sum, float *col_sumsq, float *col_sqerr,
               float *col_ssq_grad, float *batch_count, float *batch_sqerr);
 
+/* FeatureSetARD outer loop, one view: update_A! / update_A_inner! (src/featureset_ard.jl:214-294) with ISTAOptimiser.update!
+ * (src/optimizers.jl:26-62) and gamma_normal_loss + its pull-back (:154-186), run on the device against the context's
+ * resident Y (columns col_start1:col_stop1 = the view's col_range).  A starts from 0 (:286); S is the view's L x N_v
+ * feature-set matrix ROW-major (S[l*N_v + j]; the reference holds it as a sparse CSC, src/util.jl:453-477); alpha = the
+ * regularizer's alpha[cr]; lambda = the optimiser's per-factor L1 weights (update_lambda!, :189-209); ssq_grad is the
+ * optimiser's accumulator (in / out, persists across calls like A_opts); A and ssq_grad are L x K with the factor index
+ * contiguous (A[l*K + k]).  On return A = A_best, *best_loss its loss, *epochs_run the updates performed, and
+ * beta[:, cr] = (alpha0 - 1) (v0 + A'S) (:292) is written to beta_out (K x N_v column-major, may be NULL) and into the
+ * device copy of the Y regularizer's beta when one is attached (pmf_add_yreg_fsard). */
+int pmf_fsard_update_A(pmf_ctx *ctx, int64_t col_start1, int64_t col_stop1, int L, const float *S, const float *alpha,
+                       const float *lambda, float alpha0, float v0, float lr, float *ssq_grad, float *A, int max_epochs,
+                       int term_iter, double atol, double *best_loss, int *epochs_run, float *beta_out);
+
 /* Arithmetic of the three matrix products of the fused data pass (no reference counterpart: the reference computes
  * in Float32 on the GPU, src/fit.jl:24 via MatFac):
  *   PMF_PREC_F32    (default) exact f32 MFMA, v_mfma_f32_32x32x2_f32

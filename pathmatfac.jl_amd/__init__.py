@@ -16,3 +16,5 @@ from .fit import (mf_fit_, mf_fit_adapt_lr_, init_theta_, init_factors_, constru
 from . import featureset_ard  # noqa: F401
 from .featureset_ard import update_A_, update_lambda_  # noqa: F401
 from .transform import transform  # noqa: F401
+from . import model_io  # noqa: F401
+from .model_io import save_params_npz, load_params_npz  # noqa: F401

@@ -50,7 +50,7 @@ EXPORTS = [
     "pmf_grad_device_ptr", "pmf_get_grad", "pmf_forward", "pmf_stats", "pmf_kernel_time", "pmf_synth_data",
     "pmf_set_precision", "pmf_get_precision",
     "pmf_comm_get_unique_id", "pmf_comm_init", "pmf_comm_init_host", "pmf_comm_destroy", "pmf_comm_set_chunks",
-    "pmf_comm_info", "pmf_comm_allreduce", "pmf_get_opt_state",
+    "pmf_comm_info", "pmf_comm_allreduce", "pmf_get_opt_state", "pmf_fsard_update_A",
 ]
 
 COMM_ID_BYTES = 128
@@ -364,6 +364,27 @@ class Context:
         acc, mom = np.zeros(shape, np.float32, order="F"), np.zeros(shape, np.float32, order="F")
         self._chk(self.lib.pmf_get_opt_state(self._h, PARAM[which], int(view), _fp(acc), _fp(mom)))
         return acc, mom
+
+    def fsard_update_A(self, start1, stop1, S, alpha, lam, alpha0, v0, lr, ssq_grad, max_epochs=1000, term_iter=20,
+                       atol=1e-5):
+        """update_A! for one view on the device (pmf_fsard_update_A).  S: L x Nv, ssq_grad: L x K (updated in place).
+        Returns (A [L x K], beta [K x Nv], best_loss, epochs_run)."""
+        S = np.ascontiguousarray(S, dtype=np.float32)
+        L, Nv = S.shape
+        if Nv != stop1 - start1 + 1:
+            raise PMFError("S must have one column per column of the view")
+        al = np.ascontiguousarray(alpha, dtype=np.float32)
+        lm = np.ascontiguousarray(lam, dtype=np.float32)
+        if ssq_grad.dtype != np.float32 or not ssq_grad.flags.c_contiguous or ssq_grad.shape != (L, self.K):
+            raise PMFError("ssq_grad must be a C-contiguous float32 L x K array")
+        A = np.zeros((L, self.K), np.float32)
+        beta = np.zeros((self.K, Nv), np.float32, order="F")
+        best, ep = C.c_double(0), C.c_int(0)
+        self._chk(self.lib.pmf_fsard_update_A(self._h, C.c_int64(start1), C.c_int64(stop1), int(L), _fp(S), _fp(al), _fp(lm),
+                                              C.c_float(alpha0), C.c_float(v0), C.c_float(lr), _fp(ssq_grad), _fp(A),
+                                              int(max_epochs), int(term_iter), C.c_double(atol), C.byref(best), C.byref(ep),
+                                              _fp(beta)))
+        return A, beta, best.value, ep.value
 
     def forward(self):
         Z = np.zeros((self.M, self.N), np.float32, order="F")

@@ -81,27 +81,36 @@ def update_A_inner_(A, S, Yv, alpha, alpha0, v0, lr, lam, ssq_grad, max_epochs=1
     return best
 
 
-def update_A_(reg, Y, max_epochs=1000, term_iter=20, atol=1e-5, verbosity=1, print_prefix="", print_iter=100):
-    """update_A! (featureset_ard.jl:278-294): per view, A <- 0, ISTA fit, then beta[:, cr] = beta0*(v0 + A'S)."""
-    import torch
-    dev = _device()
-    beta0 = float(reg.alpha0) - 1.0
+def update_A_(reg, Y, max_epochs=1000, term_iter=20, atol=1e-5, verbosity=1, print_prefix="", print_iter=100, ctx=None):
+    """update_A! (featureset_ard.jl:278-294): per view, A <- 0, ISTA fit, then beta[:, cr] = beta0*(v0 + A'S) -- on the
+    device (pmf_fsard_update_A: the whole ISTA loop runs in two small HIP kernels per iteration, no torch).  `ctx`: the
+    model's context (its resident Y is refreshed from `Y`, K x N floats); without one a scratch context is made."""
+    from ._lib import Context
+    K, N = Y.shape
+    own = ctx is None
+    if own:
+        ctx = Context(0)
+        ctx.set_data(np.full((1, N), np.nan, dtype=np.float32))
+        ctx.set_factors(np.zeros((K, 1), np.float32), Y)
+    else:
+        ctx.set_Y(Y)
     if getattr(reg, "ssq_grad", None) is None:              # ISTAOptimiser state persists across calls (optimizers.jl:34-37)
         reg.ssq_grad = tuple(np.full(A.shape, 1e-8, dtype=np.float32) for A in reg.A)
     losses = []
-    for v, (cr, A, S) in enumerate(zip(reg.col_ranges, reg.A, reg.S)):
-        sl = cr.slice0()
-        A_t = torch.zeros(A.shape, dtype=torch.float32, device=dev)                       # A .= 0 (:286)
-        S_t = torch.as_tensor(np.ascontiguousarray(S), device=dev)
-        Y_t = torch.as_tensor(np.ascontiguousarray(Y[:, sl], dtype=np.float32), device=dev)
-        al = torch.as_tensor(np.ascontiguousarray(reg.alpha[sl]), device=dev)
-        lam = torch.as_tensor(np.ascontiguousarray(reg.lambda_[v]), device=dev)
-        ssq = torch.as_tensor(np.ascontiguousarray(reg.ssq_grad[v]), device=dev)
-        best = update_A_inner_(A_t, S_t, Y_t, al, float(reg.alpha0), float(reg.v0), float(reg.lr), lam, ssq,
-                               max_epochs=max_epochs, term_iter=term_iter, atol=atol, verbosity=verbosity,
-                               print_prefix=print_prefix + "    ", print_iter=print_iter)
-        losses.append(best)
-        A[...] = A_t.cpu().numpy()
-        reg.ssq_grad[v][...] = ssq.cpu().numpy()
-        reg.beta[:, sl] = (beta0 * (float(reg.v0) + (A_t.T @ S_t))).cpu().numpy()          # :292
+    try:
+        for v, (cr, A, S) in enumerate(zip(reg.col_ranges, reg.A, reg.S)):
+            sl = cr.slice0()
+            ssq = np.ascontiguousarray(reg.ssq_grad[v], dtype=np.float32)
+            A_new, beta, best, _ = ctx.fsard_update_A(cr.start, cr.stop, S, reg.alpha[sl], reg.lambda_[v], float(reg.alpha0),
+                                                      float(reg.v0), float(reg.lr), ssq, max_epochs=max_epochs,
+                                                      term_iter=term_iter, atol=atol)
+            losses.append(best)
+            A[...] = A_new
+            reg.ssq_grad[v][...] = ssq
+            reg.beta[:, sl] = beta                                                           # :292
+            if verbosity > 1:
+                print(f"{print_prefix}    View {v + 1}: final loss {best}")
+    finally:
+        if own:
+            ctx.close()
     return losses

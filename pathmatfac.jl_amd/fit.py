@@ -517,7 +517,7 @@ def fit_feature_set_ard_(model, lr=1.0, capacity=10 ** 8, max_epochs=1000, fsard
     beta_old = orig_reg.beta.copy()
     for it in range(1, fsard_max_iter + 1):
         update_A_(orig_reg, mf.Y, max_epochs=fsard_max_A_iter, term_iter=50, print_prefix=n_pref, print_iter=100,
-                  verbosity=verbosity)                                         # :850
+                  verbosity=verbosity, ctx=model.device_context())             # :850 (the ISTA loop runs on the device)
         d = beta_old - orig_reg.beta
         beta_diff = float(np.sum(d * d) / np.sum(orig_reg.beta * orig_reg.beta))   # :856-858
         if verbosity > 0:

@@ -119,3 +119,85 @@ def test_full_fit_orchestration_featureset_ard(pkg):
     ssq = np.sum(mf.Y.astype(np.float64) ** 2, axis=1)
     assert np.all(np.diff(ssq) <= 1e-6)                                                  # reorder_by_importance!
     model.release_device()
+
+
+def test_update_A_kernel_on_a_wide_view_matches_numpy_restatement(pkg, ctx):
+    """pmf_fsard_update_A at a realistic shape (40 feature sets x K = 64 over a 3000-column view inside a 5000-column
+    model: several column slices per workgroup, sparse S), the ISTA loop entirely on the device, against
+    oracle/fsard_oracle.py in float64: A_best, the optimiser's accumulator, beta and the best loss."""
+    rng = np.random.default_rng(35)
+    K, N, L, c0, c1 = 64, 5000, 40, 1001, 4000
+    Nv = c1 - c0 + 1
+    S = np.zeros((L, Nv), np.float32)
+    for l in range(L):
+        idx = rng.choice(Nv, size=60, replace=False)
+        S[l, idx] = 1.0 / np.sqrt(60.0)                               # featuresets_to_csc: 1/sqrt(|set|)
+    Y = (rng.standard_normal((K, N)) * 0.05).astype(np.float32)
+    for k in range(8):
+        Y[k, c0 - 1 + np.nonzero(S[3 * k])[0]] += 1.0                  # factor k loads on feature set 3k
+    alpha = np.full(Nv, 1.01, np.float32)
+    lam = (0.02 + 0.02 * rng.random(K)).astype(np.float32)
+    alpha0, v0, lr = 1.01, 0.8, 0.05
+    ctx.set_data(np.full((1, N), np.nan, np.float32))
+    ctx.set_factors(np.zeros((K, 1), np.float32), Y)
+    ctx.clear_yreg()
+    ctx.add_yreg_fsard(np.full(N, 1.01, np.float32), np.full((K, N), 0.01, np.float32))
+    ssq = np.full((L, K), 1e-8, np.float32)
+    A, beta, best, epochs = ctx.fsard_update_A(c0, c1, S, alpha, lam, alpha0, v0, lr, ssq, max_epochs=150, term_iter=30, atol=1e-5)
+    Ao = np.zeros((L, K))
+    ssqo = np.full((L, K), 1e-8)
+    best_o = fo.update_A_inner(Ao, S.astype(np.float64), Y[:, c0 - 1:c1].astype(np.float64), alpha.astype(np.float64), alpha0, v0,
+                               lr, lam.astype(np.float64), ssqo, max_epochs=150, term_iter=30, atol=1e-5)
+    assert float(Ao.max()) > 0.05 and epochs >= 30
+    assert abs(best - best_o) <= 2e-5 * abs(best_o), (best, best_o)
+    assert rel_err(A, Ao) <= 5e-3, rel_err(A, Ao)
+    assert rel_err(ssq, ssqo) <= 5e-3
+    assert rel_err(beta, (alpha0 - 1) * (v0 + Ao.T @ S.astype(np.float64))) <= 5e-3
+    # ... and the regularizer's device beta took the view's columns (the next epoch's k_reg_step reads it): one
+    # Y-regularizer evaluation must equal the closed form with the new beta inside the view and the old one outside
+    ctx.set_optimizer("adagrad", lr=1e-6)
+    o = ctx.make_opts(update_Y=True)
+    ctx.epoch_begin(o)
+    ctx.epoch_step_shared(o)
+    _, shared = ctx.epoch_loss()
+    bfull = np.full((K, N), 0.01)
+    bfull[:, c0 - 1:c1] = beta
+    want = np.sum((0.5 + 1.01) * np.log1p((0.5 / bfull) * Y.astype(np.float64) ** 2))
+    assert abs(shared - want) <= 1e-4 * want, (shared, want)
+
+
+def test_theta_delta_em_matches_independent_oracle(pkg):
+    """theta_delta_em (src/fit.jl:326-375) and its moment estimators (:297-311): the product's EM (device statistics through
+    pmf_stats + host updates, pathmatfac.jl_amd/fit.py) against oracle/em_oracle.py, an independent dense-numpy
+    restatement of the reference's Julia -- same inputs, both update-prior modes ("EM" and "EB", :466-481)."""
+    from oracle import em_oracle
+    import test_gpu_host as th
+    for update_priors in (True, False):
+        model = th.reference_fit_setup(pkg, seed=11)
+        rng = np.random.default_rng(12)
+        mf = model.matfac
+        ct = mf.col_transform
+        M, N = model.data.shape
+        # a model in the state init_batch_effects! hands to the EM: least-squares theta, delta2 and sigma2 from residual variances
+        model.data[rng.random((M, N)) < 0.1] = np.nan
+        ct.unwrapped(3).mu[...] = 0.3 * rng.standard_normal(N)
+        for v in ct.unwrapped(4).theta.values:
+            v[...] = 0.5 * rng.standard_normal(v.shape)
+        mf.X[...] = 0.3 * rng.standard_normal(mf.X.shape)
+        mf.Y[...] = 0.3 * rng.standard_normal(mf.Y.shape)
+        sigma2 = (0.5 + rng.random(N)).astype(np.float64)
+        theta_ba = ct.unwrapped(4).theta
+        delta2 = [(0.5 + rng.random(v.shape)).astype(np.float64) for v in theta_ba.values]
+        views = [dict(start1=cr.start, stop1=cr.stop, batch_of_row=np.asarray(rb), logdelta=ld.copy(), theta=t.copy())
+                 for cr, rb, ld, t in zip(theta_ba.col_ranges, theta_ba.row_batches, ct.unwrapped(2).logdelta.values, theta_ba.values)]
+        want_theta, want_d2, want_diffs = em_oracle.theta_delta_em(
+            model.data, mf.X, mf.Y, ct.unwrapped(1).logsigma, ct.unwrapped(3).mu, views, ["normal"] * N, delta2, sigma2,
+            update_priors=update_priors, max_iter=25, rtol=1e-10)
+        got_theta, got_d2 = pkg.theta_delta_em(model, [d.copy() for d in delta2], sigma2.copy(), update_priors=update_priors,
+                                               batch_em_max_iter=25, batch_em_rtol=1e-10, verbosity=0)
+        assert len(want_diffs) >= 5
+        for g, w in zip(got_theta, want_theta):
+            assert rel_err(g, w) <= 2e-4, rel_err(g, w)
+        for g, w in zip(got_d2, want_d2):
+            assert rel_err(g, w) <= 2e-4, rel_err(g, w)
+        model.release_device()
