@@ -192,6 +192,13 @@ struct SbSplitArgs {
   char *out;
 };
 
+// pmf_fused_sb2_kernel (32 < K <= 64, four waves x two row blocks): LDS footprint
+struct Sb2Cfg {
+  static constexpr size_t lds_bytes = (2 * 2 * 4096 + 4096 + 8 * 2 * 4096 + 4 * 8192 + 4 * 4096 + 8 * PMF_BN * 4 + 16 + 8 * 4 + 15) / 16 * 16;
+  static constexpr size_t lds_batch(int n_bv) { return PMF_BN * 16 * sizeof(float2) + (size_t)4 * 2 * n_bv * 32; }
+  static constexpr int max_bv = PMF_MAXV;
+};
+
 // transposed LDS read of eight bf16 (two ds_read_b64_tr_b16)
 __device__ __forceinline__ bf16x8 pmf_sb_tr8(const char *p0, const char *p1) {
   typedef s16x4 __attribute__((address_space(3))) * lds_p;
@@ -304,6 +311,8 @@ int pmf_launch_fused_sb_1(PmfDynLds *cache, hipStream_t stream, const FusedArgs 
 int pmf_launch_fused_sb_2(PmfDynLds *cache, hipStream_t stream, const FusedArgs &a, int grid, bool batch, bool mixed, bool want_gx, bool want_gy);
 int pmf_launch_fused_sb_1_bf16(PmfDynLds *cache, hipStream_t stream, const FusedArgs &a, int grid, bool batch, bool mixed, bool want_gx, bool want_gy);
 int pmf_launch_fused_sb_2_bf16(PmfDynLds *cache, hipStream_t stream, const FusedArgs &a, int grid, bool batch, bool mixed, bool want_gx, bool want_gy);
+int pmf_launch_fused_sb2(PmfDynLds *cache, hipStream_t stream, const FusedArgs &a, int grid, bool batch, bool mixed, bool want_gx, bool want_gy);
+int pmf_launch_fused_sb2_bf16(PmfDynLds *cache, hipStream_t stream, const FusedArgs &a, int grid, bool batch, bool mixed, bool want_gx, bool want_gy);
 int pmf_launch_fused_sb4_4(PmfDynLds *cache, hipStream_t stream, const FusedArgs &a, int grid, bool batch, bool mixed, bool want_gx, bool want_gy);
 int pmf_launch_fused_sb4_4_bf16(PmfDynLds *cache, hipStream_t stream, const FusedArgs &a, int grid, bool batch, bool mixed, bool want_gx, bool want_gy);
 int pmf_launch_sb4_split(hipStream_t stream, const Sb4SplitArgs &a);

@@ -1818,8 +1818,11 @@ static int launch_fused_chunk(pmf_ctx *c, const FusedGeom &g, int s, bool want_g
   if (g.sb) {
     const bool d16 = c->store == PMF_STORE_BF16;
     typedef int (*sb_fn)(PmfDynLds *, hipStream_t, const FusedArgs &, int, bool, bool, bool, bool);
+    // K in 33..64: the four-wave, two-row-block variant (pmf_fused_sb2.hip.inc); PMF_SB2=0 selects the eight-wave one
+    static const bool use_sb2 = !(getenv("PMF_SB2") && atoi(getenv("PMF_SB2")) == 0);
     const sb_fn fn = c->KB == 1 ? (d16 ? pmf_launch_fused_sb_1_bf16 : pmf_launch_fused_sb_1)
-                   : c->KB == 2 ? (d16 ? pmf_launch_fused_sb_2_bf16 : pmf_launch_fused_sb_2)
+                   : c->KB == 2 ? (use_sb2 ? (d16 ? pmf_launch_fused_sb2_bf16 : pmf_launch_fused_sb2)
+                                           : (d16 ? pmf_launch_fused_sb_2_bf16 : pmf_launch_fused_sb_2))
                                 : (d16 ? pmf_launch_fused_sb4_4_bf16 : pmf_launch_fused_sb4_4);
     rc = fn(&c->dyn_lds, c->stream, a, grid, batch, c->mixed, want_gx, want_gy);
     c->sb_launches += 1;
