@@ -278,7 +278,8 @@ struct PmfDTile<true> {
 #define PMF_LS 2   // column tiles per unit (4 was measured: more per-tile state in registers, more spills, 19.6 vs 13.5 ms)
 
 struct LayerPassArgs {
-  const float *D;
+  const void *D;        // tile-major f32 or bf16 (d_bf16)
+  int32_t d_bf16;
   int64_t nRB;
   const float *X, *Y;
   const float4 *colp;
@@ -307,6 +308,11 @@ int pmf_launch_fused_exact_12(PmfDynLds *cache, hipStream_t stream, const FusedA
 int pmf_launch_fused_exact_21(PmfDynLds *cache, hipStream_t stream, const FusedArgs &a, int grid, bool batch, bool mixed);
 int pmf_launch_fused_exact_31(PmfDynLds *cache, hipStream_t stream, const FusedArgs &a, int grid, bool batch, bool mixed);
 int pmf_launch_fused_exact_41(PmfDynLds *cache, hipStream_t stream, const FusedArgs &a, int grid, bool batch, bool mixed);
+int pmf_launch_fused_exact_11_bf16(PmfDynLds *cache, hipStream_t stream, const FusedArgs &a, int grid, bool batch, bool mixed);
+int pmf_launch_fused_exact_12_bf16(PmfDynLds *cache, hipStream_t stream, const FusedArgs &a, int grid, bool batch, bool mixed);
+int pmf_launch_fused_exact_21_bf16(PmfDynLds *cache, hipStream_t stream, const FusedArgs &a, int grid, bool batch, bool mixed);
+int pmf_launch_fused_exact_31_bf16(PmfDynLds *cache, hipStream_t stream, const FusedArgs &a, int grid, bool batch, bool mixed);
+int pmf_launch_fused_exact_41_bf16(PmfDynLds *cache, hipStream_t stream, const FusedArgs &a, int grid, bool batch, bool mixed);
 int pmf_launch_fused_sb_1(PmfDynLds *cache, hipStream_t stream, const FusedArgs &a, int grid, bool batch, bool mixed, bool want_gx, bool want_gy);
 int pmf_launch_fused_sb_2(PmfDynLds *cache, hipStream_t stream, const FusedArgs &a, int grid, bool batch, bool mixed, bool want_gx, bool want_gy);
 int pmf_launch_fused_sb_1_bf16(PmfDynLds *cache, hipStream_t stream, const FusedArgs &a, int grid, bool batch, bool mixed, bool want_gx, bool want_gy);
@@ -318,6 +324,6 @@ int pmf_launch_fused_sb4_4_bf16(PmfDynLds *cache, hipStream_t stream, const Fuse
 int pmf_launch_sb4_split(hipStream_t stream, const Sb4SplitArgs &a);
 int pmf_launch_sb_split_1(hipStream_t stream, const SbSplitArgs &a);
 int pmf_launch_sb_split_2(hipStream_t stream, const SbSplitArgs &a);
-int pmf_launch_layer_pass(PmfDynLds *cache, hipStream_t stream, int KB, int lnw, bool mixed, int grid, const LayerPassArgs &a);
+int pmf_launch_layer_pass(PmfDynLds *cache, hipStream_t stream, int KB, int lnw, bool mixed, int grid, const LayerPassArgs &a);   // (a.d_bf16 picks the storage variant)
 int pmf_launch_layer_map(hipStream_t stream, const LayerMapArgs &m);
 #endif

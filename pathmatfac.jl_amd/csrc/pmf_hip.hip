@@ -1826,17 +1826,19 @@ static int launch_fused_chunk(pmf_ctx *c, const FusedGeom &g, int s, bool want_g
                                 : (d16 ? pmf_launch_fused_sb4_4_bf16 : pmf_launch_fused_sb4_4);
     rc = fn(&c->dyn_lds, c->stream, a, grid, batch, c->mixed, want_gx, want_gy);
     c->sb_launches += 1;
-  } else if (c->store == PMF_STORE_BF16) {
-    return pmf_fail("a data matrix stored as bf16 (PMF_STORE_BF16) is read by the split-bf16 data pass only: "
-                    "pmf_set_precision(ctx, PMF_PREC_BF16X3), K <= 64 or 96 < K <= 128, at most 15 batches per view");
-  } else
-  switch (c->KB * 10 + g.RBW) {
-    case 11: rc = pmf_launch_fused_exact_11(&c->dyn_lds, c->stream, a, grid, batch, c->mixed); break;
-    case 12: rc = pmf_launch_fused_exact_12(&c->dyn_lds, c->stream, a, grid, batch, c->mixed); break;
-    case 21: rc = pmf_launch_fused_exact_21(&c->dyn_lds, c->stream, a, grid, batch, c->mixed); break;
-    case 31: rc = pmf_launch_fused_exact_31(&c->dyn_lds, c->stream, a, grid, batch, c->mixed); break;
-    case 41: rc = pmf_launch_fused_exact_41(&c->dyn_lds, c->stream, a, grid, batch, c->mixed); break;
-    default: return pmf_fail("unsupported KB=%d", c->KB);
+  } else {
+    typedef int (*ex_fn)(PmfDynLds *, hipStream_t, const FusedArgs &, int, bool, bool);
+    const bool d16 = c->store == PMF_STORE_BF16;
+    ex_fn fn = nullptr;
+    switch (c->KB * 10 + g.RBW) {
+      case 11: fn = d16 ? pmf_launch_fused_exact_11_bf16 : pmf_launch_fused_exact_11; break;
+      case 12: fn = d16 ? pmf_launch_fused_exact_12_bf16 : pmf_launch_fused_exact_12; break;
+      case 21: fn = d16 ? pmf_launch_fused_exact_21_bf16 : pmf_launch_fused_exact_21; break;
+      case 31: fn = d16 ? pmf_launch_fused_exact_31_bf16 : pmf_launch_fused_exact_31; break;
+      case 41: fn = d16 ? pmf_launch_fused_exact_41_bf16 : pmf_launch_fused_exact_41; break;
+      default: return pmf_fail("unsupported KB=%d", c->KB);
+    }
+    rc = fn(&c->dyn_lds, c->stream, a, grid, batch, c->mixed);
   }
   PMFCHK(rc);
   HIPCHK(hipEventRecord(ev.second, c->stream));   // the events bracket pmf_fused_kernel alone (= rocprofv3's kernel duration)
@@ -1915,7 +1917,7 @@ static int launch_layer_grad(pmf_ctx *c, const pmf_fit_opts *o, bool with_loss) 
 static bool layer_pass_eligible(pmf_ctx *c) {
   const char *e = getenv("PMF_LAYER_OLD");
   if (e && atoi(e) == 1) return false;
-  return c->KB <= 4 && (c->n_bv == 0 || c->btd_ok) && c->store == PMF_STORE_F32;   // (bf16 storage: the scalar kernel reads it)
+  return c->KB <= 4 && (c->n_bv == 0 || c->btd_ok);
 }
 static int launch_layer_pass(pmf_ctx *c, const pmf_fit_opts *o, bool with_loss) {
   const char *lnwenv = getenv("PMF_LAYER_NW");
@@ -1938,7 +1940,7 @@ static int launch_layer_pass(pmf_ctx *c, const pmf_fit_opts *o, bool with_loss) 
   }
   LayerPassArgs a;
   memset(&a, 0, sizeof(a));
-  a.D = (const float *)c->D; a.nRB = c->nRB; a.X = c->P[0].p; a.Y = c->P[1].p; a.colp = c->colp; a.bor = c->bor;
+  a.D = c->D; a.d_bf16 = c->store == PMF_STORE_BF16; a.nRB = c->nRB; a.X = c->P[0].p; a.Y = c->P[1].p; a.colp = c->colp; a.bor = c->bor;
   a.btd = c->n_bv > 0 ? c->btd : nullptr; a.LG = c->LG; a.loss_partial = with_loss ? c->loss_partial : nullptr;
   a.M = c->M; a.N = c->N; a.n_bv = c->n_bv; a.n_ct = (int)n_ct; a.n_rp = (int)n_rp; a.n_seg = (int)n_seg; a.R = (int)R;
   PMFCHK(pmf_launch_layer_pass(&c->dyn_lds, c->stream, c->KB, lnw, c->mixed, grid, a));

@@ -291,3 +291,39 @@ def test_bf16_stored_data_fit_and_layers(sctx):
     ro2 = m.fit(lr=1.0, **kw)
     np.testing.assert_allclose(r2["loss"], ro2["loss"], rtol=5e-5)
     ctx.set_data(p["D"])            # back to f32 storage for the tests that follow
+
+
+@pytest.mark.parametrize("name", ["ragged_k64_nan", "mixed_batch_nan_k32", "k128_ragged", "k100", "many_panels_k8"])
+def test_bf16_stored_data_through_the_exact_kernel(ctx, name):
+    """PMF_STORE_BF16 with the default precision: the exact-f32 kernels (data pass and MFMA layer pass) read the bf16
+    tiles too (two 1-KiB loads per tile, converted in the epilogue).  Oracle on the rounded matrix, usual tolerances."""
+    kw = dict(CASES[name] if name in CASES else CASES4[name])
+    if name == "mixed_batch_nan_k32":
+        kw["layer_regs"] = True
+    p = make_problem(seed=23, **kw)
+    p["D"] = np.asfortranarray(bf16_round(p["D"]))
+    to_context(p, ctx)
+    ctx.set_data(p["D"], store="bf16")
+    try:
+        n0 = ctx.get_precision()[1]
+        loss, g = grads_of(ctx, p, update_X=True, update_Y=True)
+        assert ctx.get_precision() == ("f32", n0)
+        m = to_oracle(p)
+        m.m.n_xreg = 0
+        m.m.n_yreg = 0
+        _, gd = m.loss_and_grads(update_X=True, update_Y=True)
+        assert abs(loss - gd["data_loss"]) <= LOSS_RTOL * abs(gd["data_loss"]) + 1e-6, (loss, gd["data_loss"])
+        assert rel_err(g["X"], gd["X"]) <= GRAD_TOL and rel_err(g["Y"], gd["Y"]) <= GRAD_TOL
+        if p["batch_views"]:
+            lossl, gl = grads_of(ctx, p, update_col_layers=True)
+            ml = to_oracle(p)
+            ml.m.has_colreg = 0
+            ml.m.has_batchreg = 0
+            _, go = ml.loss_and_grads(update_col_layers=True)
+            assert abs(lossl - go["data_loss"]) <= LOSS_RTOL * abs(go["data_loss"])
+            assert rel_err(gl["mu"], go["mu"]) <= GRAD_TOL
+            for v in range(len(p["batch_views"])):
+                assert rel_err(gl["theta"][v], go["theta"][v]) <= GRAD_TOL
+                assert rel_err(gl["logdelta"][v], go["logdelta"][v]) <= GRAD_TOL
+    finally:
+        ctx.set_data(p["D"])
