@@ -251,10 +251,15 @@ def main():
         # committed under profiles/; reported only when it was measured for exactly this workload
         try:
             tr = json.loads((ROOT / "profiles" / "traffic_latest.json").read_text())
+            trk = None
             wl = tr["workload"]
-            if (wl["M"], wl["N"], wl["K"], wl["n_gpus"]) == (M, N, K, world):
-                key = "split_bf16" if split_main else None
-                trk = tr[key] if key else tr
+            if (wl["M"], wl["N"], wl["K"], wl["n_gpus"]) == (M, N, K, world) and args.store == "f32":
+                trk = tr["split_bf16"] if split_main else tr
+            c4 = tr.get("config4_shard")
+            if c4 and split_main and (c4["workload"]["M"], c4["workload"]["N"], c4["workload"]["K"], c4["workload"]["n_gpus"],
+                                      c4["workload"]["store"]) == (M, N, K, world, args.store):
+                trk = c4
+            if trk is not None:
                 out["roofline"]["traffic"] = trk["hbm_read_bytes_per_launch"] + trk["hbm_write_bytes_per_launch"]
                 out["roofline"]["traffic_source"] = trk["source"]
         except (OSError, KeyError, ValueError):
@@ -264,6 +269,12 @@ def main():
             t_epoch = cpu_baseline(N, K, rows, ep, seed, args.optimizer, lr)
             from oracle import pmf_oracle as po
             ncores = int(po.get_lib(32).lib.o_num_threads())     # OpenMP threads the oracle actually used
+            # the reference's own CPU-runnable case (configs[0]) and configs[1], whole, on the same cores
+            extra = {}
+            for tag, (m0, n0, k0, ep0) in (("configs[0] 500x200 K=4", (500, 200, 4, 50)), ("configs[1] 20000x10000 K=32", (20000, 10000, 32, 2))):
+                te = cpu_baseline(n0, k0, m0, ep0, seed, args.optimizer, lr)
+                extra[tag] = {"value": 1.0 / te, "unit": "iters/s", "epochs_timed": ep0}
+            out["cpu_baseline_other_configs"] = extra
             out["cpu_baseline"] = {"value": 1.0 / (t_epoch * M / rows), "unit": "iters/s", "cores": ncores,
                                    "kind": "port",
                                    "sample": f"CPU oracle (float build, OpenMP) on {rows} of {M} rows x {N} cols, K={K}, "
