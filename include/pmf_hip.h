@@ -231,6 +231,12 @@ int pmf_comm_allreduce(pmf_ctx *ctx, void *host_buf, int64_t count, int dtype, i
 int pmf_comm_info(pmf_ctx *ctx, int *rank, int *nranks, int *transport, int *n_chunks, int *reserved_cus,
                   int64_t *n_collectives);
 
+/* Diagnostics: the batch-layer variant the last data pass took (0 none, 1 LDS table with panel-local slots, 2 per-entry
+ * gathers), the last layer pass (1 MFMA layer pass, 2 VALU kernel) and the columns of the dense batch table.  Views with
+ * more than 15 batches stay on variant 1 as long as no 256-row (128-row for K > 64) panel holds more than 15 distinct
+ * batches of one view (src/batch_array.jl:78-147 places no bound on the batch count). */
+int pmf_debug_last_path(pmf_ctx *ctx, int *bmode, int *layer_path, int *slots);
+
 /* raw device addresses of the gradient buffers (float32) and their element counts, for in-place collectives */
 int pmf_grad_device_ptr(pmf_ctx *ctx, int which, void **ptr, int64_t *n_elements);
 /* copy a gradient of the last pmf_epoch_begin to the host in the reference's shape (tests / diagnostics) */

@@ -50,7 +50,7 @@ EXPORTS = [
     "pmf_grad_device_ptr", "pmf_get_grad", "pmf_forward", "pmf_stats", "pmf_kernel_time", "pmf_synth_data",
     "pmf_set_precision", "pmf_get_precision",
     "pmf_comm_get_unique_id", "pmf_comm_init", "pmf_comm_init_host", "pmf_comm_destroy", "pmf_comm_set_chunks",
-    "pmf_comm_info", "pmf_comm_allreduce", "pmf_get_opt_state", "pmf_fsard_update_A",
+    "pmf_comm_info", "pmf_comm_allreduce", "pmf_get_opt_state", "pmf_fsard_update_A", "pmf_debug_last_path",
 ]
 
 COMM_ID_BYTES = 128
@@ -450,6 +450,12 @@ class Context:
         self._chk(self.lib.pmf_comm_info(self._h, C.byref(r), C.byref(n), C.byref(t), C.byref(ch), C.byref(cu), C.byref(nc)))
         return dict(rank=r.value, nranks=n.value, transport=("none", "rccl", "host")[t.value], n_chunks=ch.value,
                     reserved_cus=cu.value, n_collectives=nc.value)
+
+    def last_path(self):
+        """Batch-layer variants of the last launches: dict(bmode=0|1|2, layer_path=0|1|2, slots=...), see pmf_hip.h."""
+        b, l, s = C.c_int(0), C.c_int(0), C.c_int(0)
+        self._chk(self.lib.pmf_debug_last_path(self._h, C.byref(b), C.byref(l), C.byref(s)))
+        return dict(bmode=b.value, layer_path=l.value, slots=s.value)
 
     def set_precision(self, mode):
         """'f32' (exact f32 MFMA, default) or 'bf16x3' (split-bf16 products where a kernel variant exists)."""

@@ -34,6 +34,7 @@ int pmf_ensure_dyn_lds(PmfDynLds *cache, const void *kern, size_t lds);
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 #define PMF_MAXV 16
+#define PMF_PM_BYTES 256   // LDS: a piece's slot -> batch map [16 views][16 slots] (fused kernels with batch layers)
 #define PMF_BN 32      // columns per tile
 #define PMF_DPAD 64    // D is padded with NaN columns to a multiple of this
 
@@ -76,7 +77,11 @@ struct FusedArgs {
   const float4 *colp;   // per column {sigma, mu, weight, meta}; meta = kind | (view+1)<<2
   const int32_t *bor;   // n_bv x M
   const float2 *btab;
-  const float2 *btd;    // dense per-column batch table [N padded][16] {delta, theta} (slot 15 = identity); null = not available
+  const float2 *btd;    // dense per-column batch table [N padded to 32][1 << nbs_shift] {delta, theta} (last slot = identity); null = not available
+  // panel-local batch slots (PanelSlots, pmf_hip.hip): slot s of (row panel rp, view v) holds batch pm[(rp*n_bv + v)*16 + s]
+  // (255 = unused); row_slot[v*M + i] = the slot of row i (15 = no batch); colview[j] = view of column j (255 = none)
+  const uint8_t *pm, *row_slot, *colview;
+  int32_t nbs_shift;
   int32_t n_bv;         // batch views
   double *loss_partial; // one slot per workgroup
   int64_t M, N;
@@ -179,8 +184,8 @@ struct SbCfg {
   static constexpr int LDSP = 2 * IMG;     // the part every product reads (hi, mid); the lo image only feeds the forward
   static constexpr size_t lds_bytes = 2 * LDSP + IMG + NW * LDSP + NW * SLAB * 4 + 8 * PMF_BN * 4 + 16 + 8 * NW;
   // batch-layer variants add the tile's dense batch table [32 columns][16] float2 and, per wave, [n_bv views][32 rows] batch ids
-  static constexpr size_t lds_batch(int n_bv) { return PMF_BN * 16 * sizeof(float2) + (size_t)NW * n_bv * 32; }
-  static constexpr int max_bv = KB == 1 ? PMF_MAXV : (int)((160 * 1024 - lds_bytes - PMF_BN * 16 * sizeof(float2)) / (NW * 32));
+  static constexpr size_t lds_batch(int n_bv) { return PMF_BN * 16 * sizeof(float2) + PMF_PM_BYTES + (size_t)NW * n_bv * 32; }
+  static constexpr int max_bv = KB == 1 ? PMF_MAXV : (int)((160 * 1024 - lds_bytes - PMF_BN * 16 * sizeof(float2) - PMF_PM_BYTES) / (NW * 32));
 };
 
 // src: [n][Kp] f32 (rows = samples of X or columns of Y, K padded to Kp); scale = colp (sigma in .x) or null.
@@ -195,7 +200,7 @@ struct SbSplitArgs {
 // pmf_fused_sb2_kernel (32 < K <= 64, four waves x two row blocks): LDS footprint
 struct Sb2Cfg {
   static constexpr size_t lds_bytes = (2 * 2 * 4096 + 4096 + 8 * 2 * 4096 + 4 * 8192 + 4 * 4096 + 8 * PMF_BN * 4 + 16 + 8 * 4 + 15) / 16 * 16;
-  static constexpr size_t lds_batch(int n_bv) { return PMF_BN * 16 * sizeof(float2) + (size_t)4 * 2 * n_bv * 32; }
+  static constexpr size_t lds_batch(int n_bv) { return PMF_BN * 16 * sizeof(float2) + PMF_PM_BYTES + (size_t)4 * 2 * n_bv * 32; }
   static constexpr int max_bv = PMF_MAXV;
 };
 
@@ -219,7 +224,7 @@ struct Sb4Cfg {
   static constexpr int XBLK = 5 * IMG;     // per 32 samples: hi, mid, lo row images + hi, mid transposed images
   static constexpr int YBLK = 3 * IMG;     // per 32 features: hi, mid, lo row images
   static constexpr size_t lds_bytes = (2 * 2 * IMG + IMG + NW * SLAB * 4 + 8 * PMF_BN * 4 + 16 + 8 * NW + 15) / 16 * 16;
-  static constexpr size_t lds_batch(int n_bv) { return PMF_BN * 16 * sizeof(float2) + (size_t)NW * n_bv * 32; }
+  static constexpr size_t lds_batch(int n_bv) { return PMF_BN * 16 * sizeof(float2) + PMF_PM_BYTES + (size_t)NW * n_bv * 32; }
   static constexpr int max_bv = PMF_MAXV;
 };
 struct Sb4SplitArgs {
@@ -229,6 +234,22 @@ struct Sb4SplitArgs {
   int32_t Ksrc, transposed;   // transposed: also write the two transposed images (X); block stride 5 images, else 3
   char *out;
 };
+// Index into the dense batch table of entry (column j, panel-local slot s) for a column of view vw (255 = none), given the
+// piece's slot -> batch map Pm (LDS, [n_bv][16]).  Unused slots and columns outside every view hit the identity slot.
+// (32-bit element index: the host keeps the table below 2^31 entries, so the load is scalar base + one offset register)
+__device__ __forceinline__ uint32_t pmf_bt_index(const FusedArgs &a, const unsigned char *Pm, int64_t j, int s, int vw) {
+  const int ident = (1 << a.nbs_shift) - 1;
+  int b = ident;
+  if (vw != 255) { const int q = Pm[vw * 16 + s]; if (q != 255) b = q; }
+  return ((uint32_t)j << a.nbs_shift) + (uint32_t)b;
+}
+
+// Entry e (= column-in-tile * 16 + slot) of the LDS batch table of the tile at column j; vw = pmf_bt_view(a, j, e).
+__device__ __forceinline__ int pmf_bt_view(const FusedArgs &a, int64_t j, int e) { return a.colview[j + (e >> 4)]; }
+__device__ __forceinline__ float2 pmf_bt_entry(const FusedArgs &a, const unsigned char *Pm, int64_t j, int e, int vw) {
+  return a.btd[pmf_bt_index(a, Pm, j + (e >> 4), e & 15, vw)];
+}
+
 // ---- the data matrix tile in registers, f32 or bf16 storage
 // bf16 device layout of D (PMF_STORE_BF16): 32 x 32 tiles of 2 KiB in the same tile order as the f32 layout; inside a
 // tile 32-bit word q*256 + lane*4 + e holds accumulator registers 8q + 2e (low half) and 8q + 2e + 1 (high half) of
@@ -284,8 +305,9 @@ struct LayerPassArgs {
   const float *X, *Y;
   const float4 *colp;
   const int32_t *bor;      // n_bv x M row -> batch (or -1)
-  const float2 *btd;       // dense batch table [N padded to 32][16] {delta, theta}; null when there are no batch views
-  float2 *LG;              // [N][16] {S_G, S_Q}, zeroed by the host before the launch
+  const float2 *btd;       // dense batch table [N padded to 32][nbs] {delta, theta}; null when there are no batch views
+  float2 *LG;              // [N][nbs] {S_G, S_Q}, zeroed by the host before the launch
+  int32_t nbs_shift;       // nbs = 1 << nbs_shift slots per column (last = identity: row in no batch); 16 without batch views
   double *loss_partial;    // one per workgroup; null = the loss is computed elsewhere (combined epochs)
   int64_t M, N;
   int32_t n_bv, n_ct, n_rp, n_seg, R;
@@ -297,7 +319,7 @@ struct LayerMapArgs {
   const float4 *colp;
   float *g_logsigma, *g_mu, *g_logdelta, *g_theta;   // any may be null
   int64_t N;
-  int32_t n_bv;
+  int32_t n_bv, nbs_shift;
   ViewDesc views[PMF_MAXV];
   int64_t val_off[PMF_MAXV];
 };
@@ -324,6 +346,7 @@ int pmf_launch_fused_sb4_4_bf16(PmfDynLds *cache, hipStream_t stream, const Fuse
 int pmf_launch_sb4_split(hipStream_t stream, const Sb4SplitArgs &a);
 int pmf_launch_sb_split_1(hipStream_t stream, const SbSplitArgs &a);
 int pmf_launch_sb_split_2(hipStream_t stream, const SbSplitArgs &a);
+size_t pmf_layer_pass_lds(int KB, int lnw, int nbs);   // dynamic LDS of the layer pass (<= 160 KiB: eligible)
 int pmf_launch_layer_pass(PmfDynLds *cache, hipStream_t stream, int KB, int lnw, bool mixed, int grid, const LayerPassArgs &a);   // (a.d_bf16 picks the storage variant)
 int pmf_launch_layer_map(hipStream_t stream, const LayerMapArgs &m);
 #endif

@@ -43,6 +43,18 @@ struct ParamBuf {  // one trainable parameter tensor with its gradient, optimize
   float bp1 = 0.f, bp2 = 0.f;  // Adam running beta powers
 };
 
+// Panel-local batch slots.  The fused kernels look the batch parameters of (row, column) up in a 16-slot per-column table
+// in LDS.  With more than 15 batches in a view the slots are numbered PER ROW PANEL: slot s of (panel, view) is the s-th
+// distinct batch among the panel's rows (rows are normally sorted by batch: a 256-row panel holds a few), slot 15 the
+// identity.  pm[(rp * n_bv + v) * 16 + s] = that batch (255 = unused), row_slot[v * M + i] = the slot of row i.
+// ok = every (panel, view) has at most 15 distinct batches; otherwise the launch takes the gather fallback.
+struct PanelSlots {
+  int64_t serial = -1;
+  int BM = 0;
+  bool ok = false;
+  uint8_t *pm = nullptr, *row_slot = nullptr;
+};
+
 // Cached work split of one column chunk of the fused data pass (see compute_work_split).
 struct WorkSplit {
   int64_t key[10] = {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1};
@@ -101,9 +113,16 @@ struct pmf_ctx {
   ViewDesc *d_views = nullptr;    // device copy of `views` for the fused kernel's global-gather fallback
   float2 *LG = nullptr;           // [N][16] {S_G, S_Q} of the layer pass (pmf_layers.hip.inc)
   int64_t LG_cap = 0;
-  float2 *btd = nullptr;          // dense per-column batch table [ceil(N/32)*32][16] (fused kernel, LDS path); see k_dense_btab
+  float2 *btd = nullptr;          // dense per-column batch table [ceil(N/32)*32][nbs] (fused kernels, layer pass); see k_dense_btab
   int64_t btd_cap = 0;
-  bool btd_ok = false;            // every view has <= 15 batches: the dense table is usable
+  bool btd_ok = false;            // the dense table is built (every view has <= 255 batches)
+  int nbs = 16;                   // slots per column of the dense table: 16, or the power of two above the largest batch count
+  int64_t colview_cap = 0;
+  uint8_t *colview = nullptr;     // [ceil(N/32)*32] view of every column, 255 = none (k_dense_btab)
+  std::vector<std::vector<int32_t>> h_bor;   // host copy of batch_of_row per view (panel-local slot maps)
+  PanelSlots pslots[3];           // panel-local batch slots for row panels of 128 / 256 / 512 rows (ensure_panel_slots)
+  int64_t views_serial = 0;       // bumped whenever a view's rows / shape change
+  int last_bmode = 0, last_layer_path = 0;   // diagnostics (pmf_debug_last_path)
   int32_t *d_val_view = nullptr;  // per flat value element: view id
   // noise model / prepared column parameters
   int32_t *colmeta = nullptr;  // kind | (view+1)<<2
@@ -250,20 +269,25 @@ struct DenseBtabArgs {
   const int32_t *colmeta;
   const float2 *btab;
   float2 *btd;
+  uint8_t *colview;
   int64_t N, Npad;
+  int32_t nbs_shift;
   ViewDesc views[PMF_MAXV];
 };
+// (nbs = 1 << nbs_shift slots per column; the LAST slot is always the identity: rows outside every batch)
 __global__ void k_dense_btab(const DenseBtabArgs a) {
   const int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-  if (e >= a.Npad * 16) return;
-  const int64_t j = e >> 4;
-  const int b = (int)(e & 15);
+  if (e >= (a.Npad << a.nbs_shift)) return;
+  const int64_t j = e >> a.nbs_shift;
+  const int b = (int)(e & ((1 << a.nbs_shift) - 1));
   float2 out = make_float2(1.f, 0.f);
+  int v = -1;
   if (j < a.N) {
-    const int v = (a.colmeta[j] >> 2) - 1;
-    if (v >= 0 && b < a.views[v].nb && b < 15) out = a.btab[a.views[v].tab_off + (j - a.views[v].c0) * a.views[v].nb + b];
+    v = (a.colmeta[j] >> 2) - 1;
+    if (v >= 0 && b < a.views[v].nb && b < (1 << a.nbs_shift) - 1) out = a.btab[a.views[v].tab_off + (j - a.views[v].c0) * a.views[v].nb + b];
   }
   a.btd[e] = out;
+  if (b == 0) a.colview[j] = (uint8_t)(v < 0 ? 255 : v);
 }
 
 // dense quadratic weights from ranges: wq[k, i] += p * w[g, k] for i in range g   (GroupRegularizer / L2Regularizer)
@@ -837,10 +861,11 @@ extern "C" int pmf_destroy(pmf_ctx *c) {
   if (c->D) (void)hipFree(c->D);
   c->D = nullptr;
   dev_free(&c->tflags);
-  dev_free(&c->bor); dev_free(&c->btab); dev_free(&c->btd); c->btd_cap = 0; c->btd_ok = false; dev_free(&c->LG); c->LG_cap = 0; dev_free(&c->d_views); c->views_dirty = true; dev_free(&c->d_val_view);
+  dev_free(&c->bor); dev_free(&c->btab); dev_free(&c->btd); c->btd_cap = 0; c->btd_ok = false; dev_free(&c->colview); c->colview_cap = 0; dev_free(&c->LG); c->LG_cap = 0; dev_free(&c->d_views); c->views_dirty = true; dev_free(&c->d_val_view);
   dev_free(&c->colmeta); dev_free(&c->colw); dev_free(&c->colp);
   dev_free(&c->ard_alpha); dev_free(&c->ard_beta);
   comm_release(c);
+  for (auto &ps : c->pslots) { dev_free(&ps.pm); dev_free(&ps.row_slot); }
   for (auto &ws : c->splits) { dev_free(&ws.wg_begin); dev_free(&ws.c_off); dev_free(&ws.c_idx); dev_free(&ws.piece_base); dev_free(&ws.d_piece_base_abs); }
   dev_free(&c->gx_part); dev_free(&c->gx_off); dev_free(&c->gx_idx);
   if (c->ev_host) (void)hipEventDestroy(c->ev_host);
@@ -898,11 +923,13 @@ static int data_shape_changed(pmf_ctx *c, int64_t M, int64_t N) {
   PMFCHK(param_alloc(c->P[2], N));
   PMFCHK(param_alloc(c->P[3], N));
   c->n_bv = 0;
+  c->h_bor.clear();
+  c->views_serial++;
   c->views.clear();
   c->views_dirty = true;
   c->val_off.clear();
   c->bvb_off.clear();
-  dev_free(&c->bor); dev_free(&c->btab); dev_free(&c->btd); c->btd_cap = 0; c->btd_ok = false; dev_free(&c->LG); c->LG_cap = 0; dev_free(&c->d_views); c->views_dirty = true; dev_free(&c->d_val_view);
+  dev_free(&c->bor); dev_free(&c->btab); dev_free(&c->btd); c->btd_cap = 0; c->btd_ok = false; dev_free(&c->colview); c->colview_cap = 0; dev_free(&c->LG); c->LG_cap = 0; dev_free(&c->d_views); c->views_dirty = true; dev_free(&c->d_val_view);
   PMFCHK(dev_alloc(&c->colmeta, (size_t)N));
   PMFCHK(dev_alloc(&c->colw, (size_t)N));
   PMFCHK(dev_alloc(&c->colp, (size_t)N));
@@ -1041,6 +1068,8 @@ extern "C" int pmf_set_n_batch_views(pmf_ctx *c, int n) {
   // AdaGrad object after halving eta: its accumulators must survive.  pmf_set_batch_view replaces what changed.
   if (n == c->n_bv && (int)c->views.size() == n && (n == 0 || c->bor)) return 0;
   c->n_bv = n;
+  c->h_bor.assign((size_t)n, std::vector<int32_t>());
+  c->views_serial++;
   c->views.assign((size_t)n, ViewDesc{0, 0, 0, 0, 0});
   c->views_dirty = true;
   c->val_off.assign((size_t)n + 1, 0);
@@ -1074,6 +1103,11 @@ extern "C" int pmf_set_batch_view(pmf_ctx *c, int v, int64_t s1, int64_t e1, int
   c->views[v].nb = nb;
   c->views_dirty = true;
   HIPCHK(hipMemcpy(c->bor + (int64_t)v * c->M, batch_of_row, sizeof(int32_t) * (size_t)c->M, hipMemcpyHostToDevice));
+  if ((int)c->h_bor.size() < c->n_bv) c->h_bor.resize((size_t)c->n_bv);
+  if (c->h_bor[(size_t)v].size() != (size_t)c->M || memcmp(c->h_bor[(size_t)v].data(), batch_of_row, sizeof(int32_t) * (size_t)c->M) != 0) {
+    c->h_bor[(size_t)v].assign(batch_of_row, batch_of_row + c->M);
+    c->views_serial++;
+  }
   if (!same_shape) {
     // (re)compute offsets for views >= v and reallocate the flat arrays once the last view is known
     for (int u = v; u < c->n_bv; ++u) {
@@ -1362,17 +1396,24 @@ static int prepare(pmf_ctx *c) {
     }
     int nb_max = 0;
     for (int v = 0; v < c->n_bv; ++v) nb_max = std::max(nb_max, (int)c->views[v].nb);
-    if (nb_max <= 15) {
-      const int64_t Npad = (c->N + 31) / 32 * 32;
-      if (Npad * 16 > c->btd_cap) {
-        PMFCHK(dev_alloc(&c->btd, (size_t)(Npad * 16), false));
-        c->btd_cap = Npad * 16;
+    int shift = 4;
+    while ((1 << shift) < nb_max + 1) ++shift;
+    const int64_t Npad = (c->N + 31) / 32 * 32;
+    if (nb_max <= 255 && (Npad << shift) < (1ll << 31)) {   // (the kernels index the table with 32 bits)
+      c->nbs = 1 << shift;
+      if (Npad * c->nbs > c->btd_cap) {
+        PMFCHK(dev_alloc(&c->btd, (size_t)(Npad * c->nbs), false));
+        c->btd_cap = Npad * c->nbs;
+      }
+      if (Npad > c->colview_cap) {
+        PMFCHK(dev_alloc(&c->colview, (size_t)Npad, false));
+        c->colview_cap = Npad;
       }
       DenseBtabArgs da;
       memset(&da, 0, sizeof(da));
-      da.colmeta = c->colmeta; da.btab = c->btab; da.btd = c->btd; da.N = c->N; da.Npad = Npad;
+      da.colmeta = c->colmeta; da.btab = c->btab; da.btd = c->btd; da.colview = c->colview; da.N = c->N; da.Npad = Npad; da.nbs_shift = shift;
       for (int v = 0; v < c->n_bv; ++v) da.views[v] = c->views[v];
-      k_dense_btab<<<nblocks(Npad * 16, 256), 256, 0, c->stream>>>(da);
+      k_dense_btab<<<nblocks(Npad * c->nbs, 256), 256, 0, c->stream>>>(da);
       HIPCHK(hipGetLastError());
       c->btd_ok = true;
     }
@@ -1484,6 +1525,8 @@ __global__ __launch_bounds__(256) void k_gx_reduce(const float *__restrict__ par
 // Geometry of one fused data pass: kernel variant, row panels, column chunks.
 struct FusedGeom {
   int NW = 8, RBW = 1, BM = 256, grid_max = 256, S = 1;
+  int bmode = 0;      // batch layers: 0 none, 1 LDS table with panel-local slots, 2 per-entry global gathers (fallback)
+  PanelSlots *ps = nullptr;
   bool sb = false;    // split-bf16 products: pmf_fused_sb_kernel (K <= 64) or pmf_fused_sb4_kernel (64 < K <= 128)
   int64_t n_rp = 0, n_ct_all = 0;
   int64_t ct0[PMF_MAX_CHUNKS], nct[PMF_MAX_CHUNKS];
@@ -1603,6 +1646,52 @@ static int harvest_events(pmf_ctx *c) {
   return 0;
 }
 
+// Panel-local batch slots for row panels of BM rows (PanelSlots): built on the host from the views' row -> batch maps,
+// cached until a view's rows change.  Returns through ps.ok whether every (panel, view) has at most 15 distinct batches.
+static int ensure_panel_slots(pmf_ctx *c, int BM, PanelSlots **out) {
+  PanelSlots &ps = c->pslots[BM == 128 ? 0 : (BM == 256 ? 1 : 2)];
+  *out = &ps;
+  if (ps.serial == c->views_serial && ps.BM == BM) return 0;
+  const int64_t n_rp = (c->M + BM - 1) / BM;
+  std::vector<uint8_t> pm((size_t)(n_rp * c->n_bv * 16), 255), rs((size_t)((int64_t)c->n_bv * c->M), 15);
+  bool ok = true;
+  std::vector<int> slot_of;
+  for (int v = 0; v < c->n_bv && ok; ++v) {
+    if ((int64_t)c->h_bor[(size_t)v].size() != c->M) { ok = false; break; }
+    const int32_t *bor = c->h_bor[(size_t)v].data();
+    slot_of.assign((size_t)std::max<int>(c->views[v].nb, 1), -1);
+    for (int64_t rp = 0; rp < n_rp && ok; ++rp) {
+      uint8_t *pmv = pm.data() + (rp * c->n_bv + v) * 16;
+      int used = 0;
+      const int64_t i1 = std::min<int64_t>(c->M, (rp + 1) * BM);
+      for (int64_t i = rp * BM; i < i1; ++i) {
+        const int b = bor[i];
+        if (b < 0) continue;             // row in no batch: identity slot 15
+        if (b > 254) { ok = false; break; }
+        int sl = slot_of[(size_t)b];
+        if (sl < 0) {
+          if (used == 15) { ok = false; break; }
+          sl = used++;
+          slot_of[(size_t)b] = sl;
+          pmv[sl] = (uint8_t)b;
+        }
+        rs[(size_t)((int64_t)v * c->M + i)] = (uint8_t)sl;
+      }
+      for (int q = 0; q < used; ++q) slot_of[pmv[q]] = -1;
+    }
+  }
+  ps.ok = ok;
+  ps.BM = BM;
+  ps.serial = c->views_serial;
+  if (ok) {
+    PMFCHK(dev_alloc(&ps.pm, pm.size(), false));
+    PMFCHK(dev_alloc(&ps.row_slot, std::max<size_t>(rs.size(), 1), false));
+    HIPCHK(hipMemcpy(ps.pm, pm.data(), pm.size(), hipMemcpyHostToDevice));
+    if (!rs.empty()) HIPCHK(hipMemcpy(ps.row_slot, rs.data(), rs.size(), hipMemcpyHostToDevice));
+  }
+  return 0;
+}
+
 // Variant and chunking of a fused data pass.
 //   variant: waves per workgroup NW and 32-row blocks per wave RBW (the workgroup's row panel is 32*NW*RBW rows)
 //     K <= 32 : 8 waves x 2 row blocks (per-tile overheads amortised over twice the MFMA work; x 1 with batch layers)
@@ -1622,7 +1711,13 @@ static FusedGeom fused_geometry(pmf_ctx *c, bool want_gx, bool want_gy, bool all
   // split-bf16 products (opt-in, pmf_set_precision): K <= 64; one row block per wave
   // (batch layers: through the dense LDS table only, i.e. <= 15 batches per view, and as many views as LDS has room for)
   const int sb_max_bv = c->KB == 1 ? SbCfg<1>::max_bv : (c->KB == 2 ? SbCfg<2>::max_bv : Sb4Cfg<4>::max_bv);
-  const bool sb_batch_ok = c->n_bv == 0 || (c->btd_ok && c->n_bv <= sb_max_bv);
+  // batch layers: the LDS-table path needs the dense table and <= 15 distinct batches per (view, row panel); every
+  // variant with batch layers has one row block per wave, so the panel height is known here
+  if (c->n_bv > 0) {
+    g.bmode = 2;
+    if (c->btd_ok && ensure_panel_slots(c, 32 * g.NW, &g.ps) == 0 && g.ps && g.ps->ok) g.bmode = 1;
+  }
+  const bool sb_batch_ok = c->n_bv == 0 || (g.bmode == 1 && c->n_bv <= sb_max_bv);
   // (K in 65..96 keeps three K blocks in the parameter buffers: no split variant is built for that stride)
   g.sb = c->precision == PMF_PREC_BF16X3 && c->KB != 3 && sb_batch_ok && (want_gx || want_gy) && !getenv("PMF_DEBUG_FLAGS");
   if (g.sb) g.RBW = 1;
@@ -1774,7 +1869,13 @@ static int launch_fused_chunk(pmf_ctx *c, const FusedGeom &g, int s, bool want_g
   a.wg_begin = ws.wg_begin;
   a.D = c->D; a.X = c->P[0].p; a.Y = c->P[1].p; a.gX = c->P[0].g; a.gY = c->P[1].g;
   a.colp = c->colp; a.bor = c->bor; a.btab = c->btab; a.loss_partial = c->loss_partial + loss_off;
-  a.btd = (c->n_bv > 0 && c->btd_ok) ? c->btd : nullptr; a.n_bv = c->n_bv;
+  a.btd = g.bmode == 1 ? c->btd : nullptr; a.n_bv = c->n_bv;
+  if (g.bmode == 1) {
+    a.pm = g.ps->pm; a.row_slot = g.ps->row_slot; a.colview = c->colview;
+    a.nbs_shift = 0;
+    while ((1 << a.nbs_shift) < c->nbs) ++a.nbs_shift;
+  }
+  c->last_bmode = g.bmode;
   a.nRB = c->nRB; a.gy_slabs = c->gy_slabs; a.slab_stride = slab_stride; a.n_rp = n_rp;
   a.M = c->M; a.N = c->N; a.n_tiles = n_rp * n_ct; a.tps = (int)tiles_per_seg; a.n_ct = (int)n_ct; a.n_cseg = (int)n_cseg;
   a.want_gx = want_gx; a.want_gy = want_gy;
@@ -1914,23 +2015,31 @@ static int launch_layer_grad(pmf_ctx *c, const pmf_fit_opts *o, bool with_loss) 
 
 // Layer-parameter gradients through the MFMA layer pass (its own loss only in layer-only epochs); K <= 64 and <= 15 batches per view, otherwise the
 // VALU kernel above (PMF_LAYER_OLD=1 forces it, for comparison).  K <= 128; views with <= 15 batches.
+static int layer_pass_waves(pmf_ctx *c) {   // waves per workgroup of the layer pass
+  const char *lnwenv = getenv("PMF_LAYER_NW");
+  return (c->KB <= 2 && !(lnwenv && atoi(lnwenv) == 4)) ? 8 : 4;
+}
 static bool layer_pass_eligible(pmf_ctx *c) {
   const char *e = getenv("PMF_LAYER_OLD");
   if (e && atoi(e) == 1) return false;
-  return c->KB <= 4 && (c->n_bv == 0 || c->btd_ok);
+  if (c->KB > 4 || (c->n_bv > 0 && !c->btd_ok)) return false;
+  // the batch table of the unit's 64 columns (nbs slots each) lives in LDS next to the Y tiles and the X panels
+  return pmf_layer_pass_lds(c->KB, layer_pass_waves(c), c->n_bv > 0 ? c->nbs : 16) <= 160 * 1024;
 }
 static int launch_layer_pass(pmf_ctx *c, const pmf_fit_opts *o, bool with_loss) {
-  const char *lnwenv = getenv("PMF_LAYER_NW");
-  const int lnw = (c->KB <= 2 && !(lnwenv && atoi(lnwenv) == 4)) ? 8 : 4;   // waves per workgroup of the layer pass
+  const int lnw = layer_pass_waves(c);
+  const int nbs = c->n_bv > 0 ? c->nbs : 16;
+  int nbs_shift = 0;
+  while ((1 << nbs_shift) < nbs) ++nbs_shift;
   const int64_t n_ct = (c->N + PMF_BN - 1) / PMF_BN, n_rp = (c->M + 32 * lnw - 1) / (32 * lnw);
   const int64_t n_seg = (n_ct + PMF_LS - 1) / PMF_LS;
   int64_t R = std::max<int64_t>(1, std::min<int64_t>(n_rp, (4ll * c->n_cu + n_seg - 1) / n_seg));
   const int grid = (int)std::min<int64_t>(n_seg * R, c->n_cu);
-  if (c->N * 16 > c->LG_cap) {
-    PMFCHK(dev_alloc(&c->LG, (size_t)(c->N * 16), false));
-    c->LG_cap = c->N * 16;
+  if (c->N * nbs > c->LG_cap) {
+    PMFCHK(dev_alloc(&c->LG, (size_t)(c->N * nbs), false));
+    c->LG_cap = c->N * nbs;
   }
-  HIPCHK(hipMemsetAsync(c->LG, 0, sizeof(float2) * (size_t)(c->N * 16), c->stream));
+  HIPCHK(hipMemsetAsync(c->LG, 0, sizeof(float2) * (size_t)(c->N * nbs), c->stream));
   if (with_loss) {
     if (grid > c->loss_cap) {
       PMFCHK(dev_alloc(&c->loss_partial, (size_t)grid));
@@ -1943,11 +2052,12 @@ static int launch_layer_pass(pmf_ctx *c, const pmf_fit_opts *o, bool with_loss) 
   a.D = c->D; a.d_bf16 = c->store == PMF_STORE_BF16; a.nRB = c->nRB; a.X = c->P[0].p; a.Y = c->P[1].p; a.colp = c->colp; a.bor = c->bor;
   a.btd = c->n_bv > 0 ? c->btd : nullptr; a.LG = c->LG; a.loss_partial = with_loss ? c->loss_partial : nullptr;
   a.M = c->M; a.N = c->N; a.n_bv = c->n_bv; a.n_ct = (int)n_ct; a.n_rp = (int)n_rp; a.n_seg = (int)n_seg; a.R = (int)R;
+  a.nbs_shift = nbs_shift;
   PMFCHK(pmf_launch_layer_pass(&c->dyn_lds, c->stream, c->KB, lnw, c->mixed, grid, a));
   LayerMapArgs m;
   memset(&m, 0, sizeof(m));
   const int fl = o->frozen_layers;
-  m.LG = c->LG; m.btd = a.btd; m.colp = c->colp; m.N = c->N; m.n_bv = c->n_bv;
+  m.LG = c->LG; m.btd = a.btd; m.colp = c->colp; m.N = c->N; m.n_bv = c->n_bv; m.nbs_shift = nbs_shift;
   m.g_logsigma = (fl & 1) ? nullptr : c->P[2].g;
   m.g_logdelta = ((fl & 2) || c->n_bv == 0) ? nullptr : c->P[4].g;
   m.g_mu = (fl & 4) ? nullptr : c->P[3].g;
@@ -2021,8 +2131,20 @@ static int epoch_open(pmf_ctx *c, const pmf_fit_opts *o) {
   return 0;
 }
 static int epoch_layer_pass(pmf_ctx *c, const pmf_fit_opts *o, bool with_loss) {
-  if (layer_pass_eligible(c)) return launch_layer_pass(c, o, with_loss);
+  if (layer_pass_eligible(c)) { c->last_layer_path = 1; return launch_layer_pass(c, o, with_loss); }
+  c->last_layer_path = 2;
   return launch_layer_grad(c, o, with_loss);
+}
+
+// Which batch-layer variants the last launches took (tests and benchmarks: a silent fall-back to the slow paths is a
+// performance bug).  bmode: 0 none, 1 LDS table with panel-local slots, 2 per-entry gathers; layer_path: 1 MFMA layer
+// pass, 2 VALU layer kernel; slots: columns of the dense batch table.
+extern "C" int pmf_debug_last_path(pmf_ctx *c, int *bmode, int *layer_path, int *slots) {
+  if (!c) return pmf_fail("null context");
+  if (bmode) *bmode = c->last_bmode;
+  if (layer_path) *layer_path = c->last_layer_path;
+  if (slots) *slots = c->nbs;
+  return 0;
 }
 
 extern "C" int pmf_epoch_begin(pmf_ctx *c, const pmf_fit_opts *o) {

@@ -12,7 +12,7 @@ ctx = pkg.Context(0, lib_path=(Path(os.environ["PMF_LIB"]).resolve() if os.envir
 ctx.set_data_device(None, M, N)
 ctx.set_factors((rng.standard_normal((K, M)) * 0.3).astype(np.float32), (rng.standard_normal((K, N)) * 0.3).astype(np.float32))
 ctx.set_col_params((rng.standard_normal(N) * 0.1).astype(np.float32), rng.standard_normal(N).astype(np.float32))
-nb, h = 8, N // 2
+nb, h = int(os.environ.get("PMF_NB", "8")), N // 2
 views = []
 for (s, e) in ((1, h), (h + 1, N)):
     nv = e - s + 1
@@ -27,4 +27,4 @@ for flags in (dict(update_col_layers=True), dict(update_X=True, update_Y=True, u
     r = ctx.fit(max_epochs=2, abs_tol=0, rel_tol=0, **flags)
     t0 = time.time()
     r = ctx.fit(max_epochs=5, epoch=3, abs_tol=0, rel_tol=0, **flags)
-    print(f"{M}x{N} K={K} {flags}: {(time.time()-t0)/3*1e3:.2f} ms/epoch; loss {r['loss'][0]:.5g} -> {r['loss'][-1]:.5g}")
+    print(f"{M}x{N} K={K} {flags}: {(time.time()-t0)/3*1e3:.2f} ms/epoch; loss {r['loss'][0]:.5g} -> {r['loss'][-1]:.5g} nb={nb} path={ctx.last_path()}")

@@ -4,6 +4,7 @@ import sys
 import time
 from pathlib import Path
 import numpy as np
+import os
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
 import pmf_import
 pkg = pmf_import.load()
@@ -14,7 +15,7 @@ ctx = pkg.Context(0)
 ctx.set_data_device(None, M, N)
 ctx.set_factors((rng.standard_normal((K, M)) * 0.3).astype(np.float32), (rng.standard_normal((K, N)) * 0.3).astype(np.float32))
 ctx.set_col_params((rng.standard_normal(N) * 0.1).astype(np.float32), rng.standard_normal(N).astype(np.float32))
-nb = 8
+nb = int(os.environ.get("PMF_NB", "8"))   # batches per view (rows sorted by batch)
 h = N // 2
 views = []
 for (s, e) in ((1, h), (h + 1, N)):
@@ -39,4 +40,4 @@ wall = (time.time() - t0) / 3
 ms, n = ctx.kernel_time()
 fl = 6.0 * M * N * K
 print(f"[{mode}] {M}x{N} K={K}: epoch wall {wall*1e3:.2f} ms; fused kernel {ms:.3f} ms x{n} -> {fl/ms/1e9:.1f} TF/s "
-      f"({fl/ms/1e9/157.3*100:.1f}% of f32 MFMA peak); loss {r['loss'][0]:.5g} -> {r['loss'][-1]:.5g} {r['term_code']}")
+      f"({fl/ms/1e9/157.3*100:.1f}% of f32 MFMA peak); loss {r['loss'][0]:.5g} -> {r['loss'][-1]:.5g} {r['term_code']} nb={nb} path={ctx.last_path()}")

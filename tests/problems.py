@@ -16,7 +16,7 @@ def split_ranges(n, parts):
 
 def make_problem(M, N, K, seed=0, bernoulli_frac=0.0, poisson_frac=0.0, n_views=1, batch_views=0, n_batches=4,
                  nan_frac=0.0, xreg=None, yreg=None, weights=False, col_params=False, layer_regs=False,
-                 n_groups=3, noise=0.1, scale=1.0, random_init=False):
+                 n_groups=3, noise=0.1, scale=1.0, random_init=False, batch_order="mixed"):
     rng = np.random.default_rng(seed)
     X = (rng.standard_normal((K, M)) * scale).astype(np.float32)
     Y = (rng.standard_normal((K, N)) * scale).astype(np.float32)
@@ -42,10 +42,18 @@ def make_problem(M, N, K, seed=0, bernoulli_frac=0.0, poisson_frac=0.0, n_views=
     for v in range(min(batch_views, len(view_ranges))):
         s, e = view_ranges[v]
         Nv = e - s + 1
-        bor = np.sort(rng.integers(0, n_batches, size=M)).astype(np.int32)  # contiguous batches like real data
-        if v % 2 == 1:
-            bor = rng.permutation(bor).astype(np.int32)                      # ... and a scrambled one
-        bor[:n_batches] = np.arange(n_batches)                                # every batch non-empty
+        if batch_order == "mixed":
+            bor = np.sort(rng.integers(0, n_batches, size=M)).astype(np.int32)  # contiguous batches like real data
+            if v % 2 == 1:
+                bor = rng.permutation(bor).astype(np.int32)                      # ... and a scrambled one
+            bor[:n_batches] = np.arange(n_batches)                                # every batch non-empty
+        else:
+            # "sorted": every view has contiguous batches (samples grouped by batch, as assemble_model lays them out);
+            # "random": every view scrambled.  Every batch non-empty.
+            bor = np.sort(np.concatenate([np.arange(n_batches), rng.integers(0, n_batches, size=M - n_batches)]))
+            if batch_order == "random":
+                bor = rng.permutation(bor)
+            bor = bor.astype(np.int32)
         centers_d = rng.standard_normal(n_batches)[:, None] * 0.25
         centers_t = rng.standard_normal(n_batches)[:, None] * 0.25
         bviews.append(dict(start1=s, stop1=e, batch_of_row=bor,
