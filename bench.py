@@ -128,6 +128,8 @@ def main():
                 time.sleep(0.05)
             uid = uid_file.read_bytes()
         ctx.comm_init(rank, world, uid)
+    if os.environ.get("PMF_BENCH_CHUNKS"):   # column chunks per data pass (default: 1 on one rank, up to 4 with more)
+        ctx.comm_set_chunks(int(os.environ["PMF_BENCH_CHUNKS"]))
 
     def barrier():
         if use_dist:

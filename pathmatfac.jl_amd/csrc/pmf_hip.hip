@@ -1727,7 +1727,22 @@ static FusedGeom fused_geometry(pmf_ctx *c, bool want_gx, bool want_gy, bool all
   g.grid_max = std::max(1, c->n_cu - (c->comm.nranks > 1 ? c->comm.reserve_cus : 0));
   int S = 1;
   if (allow_chunks && want_gy) {
-    S = c->n_chunks_req > 0 ? c->n_chunks_req : (c->comm.nranks > 1 ? 4 : 1);
+    S = c->n_chunks_req > 0 ? c->n_chunks_req : 1;
+    if (c->n_chunks_req <= 0 && c->comm.nranks > 1) {
+      // Automatic.  In the pipelined loop of pmf_fit the all-reduce of chunk s has until the Y step of chunk s, i.e. it
+      // runs beside the data pass of the other S - 1 chunks (this epoch's s+1.. and the next epoch's ..s-1): with one
+      // chunk the collective is fully exposed, with two or more it is hidden as long as it is shorter than (S-1)/S of a
+      // pass.  Every extra launch costs ~0.06 ms of prologue, tail and launch gap (measured with a one-rank communicator,
+      // 25000 rows x 50000, K = 64: 1 / 2 / 4 / 8 chunks = 4.27 / 4.33 / 4.45 / 4.79 ms per epoch), so: two chunks, more
+      // only while a chunk's all-reduce (~30 us + bytes / algorithm bandwidth; 60 GB/s assumed for an 8-GPU xGMI ring
+      // at these sizes, PMF_COMM_ALGBW_GBPS overrides) would not fit beside the rest of the pass.
+      const char *bw = getenv("PMF_COMM_ALGBW_GBPS");
+      const double algbw = (bw && atof(bw) > 0 ? atof(bw) : 60.0) * 1e9;
+      const double bytes = 4.0 * (double)c->Kp * (double)c->N;
+      const double t_pass = 6.0 * (double)c->M * (double)c->N * (double)c->Kp / (g.sb ? 200e12 : 115e12);
+      S = 2;
+      while (S < 4 && 30e-6 + bytes / S / algbw > t_pass * (S - 1) / S) ++S;
+    }
     // a chunk should give every workgroup a few dozen tiles at least (each launch pays its prologue and its tail)
     const int64_t min_tiles = 32ll * g.grid_max;
     while (S > 1 && (g.n_rp * g.n_ct_all) / S < min_tiles && c->n_chunks_req <= 0) --S;

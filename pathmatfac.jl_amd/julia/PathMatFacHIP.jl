@@ -47,6 +47,55 @@ function set_precision!(model, mode::Symbol)
     chk(ccall((:pmf_set_precision, LIB[]), Cint, (Ptr{Cvoid}, Cint), context!(model), code))
 end
 
+# Storage type of the device copy of D (include/pmf_hip.h): :f32 (default) or :bf16 (BASELINE configs[4], "D stored
+# bf16": rounded once at upload, everything else stays Float32).  Takes effect at the next upload of the data matrix.
+const STORE = Ref{Cint}(0)
+set_store!(mode::Symbol) = (STORE[] = mode == :f32 ? 0 : mode == :bf16 ? 1 : error("store must be :f32 or :bf16"); nothing)
+
+# ---- multi-GPU: one Julia process per GPU (analyses/scripts/julia/script_util.jl:278-306), rows sharded ----------------
+# Rank 0 creates the 128-byte RCCL id and hands it to the other ranks by any means (a file, MPI, Distributed.jl):
+#     id = PathMatFacHIP.comm_unique_id()                       # rank 0
+#     PathMatFacHIP.comm_init!(model, rank, nranks, id)         # every rank, before fit!
+# From then on mf_fit! all-reduces grad(Y), the loss and the layer gradients inside pmf_fit (DESIGN.md 5); the
+# statistics the host keeps between the GD stages go through comm_allreduce!.
+function comm_unique_id()
+    id = zeros(UInt8, 128)
+    GC.@preserve id chk(ccall((:pmf_comm_get_unique_id, LIB[]), Cint, (Ptr{UInt8},), id))
+    return id
+end
+function comm_init!(model, rank::Integer, nranks::Integer, id::Vector{UInt8}; device::Integer=rank)
+    ctx = context!(model; device=device)
+    GC.@preserve id chk(ccall((:pmf_comm_init, LIB[]), Cint, (Ptr{Cvoid}, Cint, Cint, Ptr{UInt8}), ctx, rank, nranks, id))
+end
+comm_destroy!(model) = chk(ccall((:pmf_comm_destroy, LIB[]), Cint, (Ptr{Cvoid},), context!(model)))
+comm_set_chunks!(model, n::Integer) = chk(ccall((:pmf_comm_set_chunks, LIB[]), Cint, (Ptr{Cvoid}, Cint), context!(model), n))
+# sum (op = 0) or maximum (op = 1) over the ranks of a host array, in place (Float32 or Float64)
+function comm_allreduce!(model, a::Array{T}; op::Integer=0) where {T<:Union{Float32,Float64}}
+    GC.@preserve a chk(ccall((:pmf_comm_allreduce, LIB[]), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Int64, Cint, Cint),
+                             context!(model), a, length(a), T == Float64 ? 1 : 0, op))
+    return a
+end
+
+# Adopt the host's HIP stream (AMDGPU.jl: AMDGPU.stream().stream); C_NULL = the library's own non-blocking stream.
+set_stream!(model, stream::Ptr{Cvoid}) = chk(ccall((:pmf_set_stream, LIB[]), Cint, (Ptr{Cvoid}, Ptr{Cvoid}), context!(model), stream))
+
+# update_A! of one FeatureSetARDReg view on the device (src/featureset_ard.jl:214-294): S is the view's L x N_v feature-set
+# matrix (dense, row-major for the library = the transpose of Julia's column-major N_v x L), A / ssq_grad are K x L here
+# (factor index contiguous).  Returns (best_loss, epochs_run); beta[:, cr] is updated on the device and returned in beta.
+function fsard_update_A!(model, cr::UnitRange, S_t::Matrix{Float32}, alpha::Vector{Float32}, lambda::Vector{Float32},
+                         A_t::Matrix{Float32}, ssq_t::Matrix{Float32}, beta::Matrix{Float32};
+                         alpha0::Float32, v0::Float32, lr::Float32, max_epochs::Integer=1000, term_iter::Integer=50,
+                         atol::Float64=1e-5)
+    best = Ref{Cdouble}(0.0); ep = Ref{Cint}(0)
+    L = size(S_t, 2)
+    GC.@preserve S_t alpha lambda A_t ssq_t beta chk(ccall((:pmf_fsard_update_A, LIB[]), Cint,
+        (Ptr{Cvoid}, Int64, Int64, Cint, Ptr{Cfloat}, Ptr{Cfloat}, Ptr{Cfloat}, Cfloat, Cfloat, Cfloat, Ptr{Cfloat},
+         Ptr{Cfloat}, Cint, Cint, Cdouble, Ref{Cdouble}, Ref{Cint}, Ptr{Cfloat}),
+        context!(model), cr.start, cr.stop, L, S_t, alpha, lambda, alpha0, v0, lr, ssq_t, A_t, max_epochs, term_iter, atol,
+        best, ep, beta))
+    return best[], Int(ep[])
+end
+
 function context!(model; device::Integer=0)
     ctx = get!(CTX, model) do
         p = Ref{Ptr{Cvoid}}(C_NULL)
@@ -58,7 +107,7 @@ function context!(model; device::Integer=0)
         D = f32(model.data)
         M, N = size(D)
         GC.@preserve D chk(ccall((:pmf_set_data, LIB[]), Cint, (Ptr{Cvoid}, Ptr{Cfloat}, Int64, Int64, Cint),
-                                 ctx, D, M, N, 0))
+                                 ctx, D, M, N, STORE[]))
         DATA_KEY[model] = key
     end
     return ctx
