@@ -10,6 +10,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <type_traits>
 #include <unordered_map>
 
 #include "../../include/pmf_hip.h"
@@ -142,7 +143,21 @@ __device__ __forceinline__ void pmf_store_stream(float4 *p, const float4 &v) {
 
 // Diagnostic build only (-DPMF_STAMPS): per-phase shader-cycle totals, one row of 16 counters per workgroup,
 // written to a buffer nothing else reads (cdna_hip_programming.md section 7, "In-kernel stamps").
-#ifdef PMF_STAMPS
+#if defined(PMF_STAMPS) && defined(PMF_STAMP_FROM)
+// two-stamp variant (-DPMF_STAMPS -DPMF_STAMP_FROM=a -DPMF_STAMP_TO=b): only the interval from stamp a to stamp b is timed
+// (into slot 1), so that the diagnostic costs two scalar loads and four registers instead of a stamp at every phase edge
+#define PMF_STAMP(slot)                                                                      \
+  do {                                                                                       \
+    if ((slot) == PMF_STAMP_FROM || (slot) == PMF_STAMP_TO) {                                \
+      unsigned long long t_;                                                                 \
+      __builtin_amdgcn_sched_barrier(0);                                                     \
+      asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");             \
+      __builtin_amdgcn_sched_barrier(0);                                                     \
+      if ((slot) == PMF_STAMP_TO) st_acc[1] += t_ - st_prev;                                 \
+      if ((slot) == PMF_STAMP_FROM) st_prev = t_;                                            \
+    }                                                                                        \
+  } while (0)
+#elif defined(PMF_STAMPS)
 #define PMF_STAMP(slot)                                                                      \
   do {                                                                                       \
     unsigned long long t_;                                                                   \
