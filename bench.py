@@ -66,6 +66,10 @@ def main():
                          "split-bf16 kernel; the other mode is timed afterwards on the same data and reported beside it")
     ap.add_argument("--store", default=os.environ.get("PMF_BENCH_STORE", "f32"), choices=["f32", "bf16"],
                     help="storage type of the device copy of D (bf16: BASELINE configs[4]; read by the split-bf16 pass only)")
+    ap.add_argument("--full-model", action="store_true",
+                    help="BASELINE configs[2] / configs[4] flavour (SURVEY 8d C3 / C5): 20 %% Bernoulli columns, column scale / shift, "
+                         "BatchArray scale / shift on 2 views x 8 row batches, 10 %% missing entries -- on top of the group-reg X + "
+                         "feature-set-ARD Y of the headline workload")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "0") or 0)
@@ -143,10 +147,29 @@ def main():
     X0 = (rng_x.standard_normal((K, Ml)) * 0.1).astype(np.float32)
     ctx.set_data_device(None, Ml, N, store=args.store)        # device-resident, library-owned
     ctx.set_factors(X_true, Y_true)
-    ctx.set_col_params(np.zeros(N, np.float32), np.zeros(N, np.float32))
-    ctx.set_batch_views([])
-    ctx.set_noise([(1, N)], ["normal"], np.ones(N, np.float32))
-    ctx.synth_data(seed=seed + 17 * (rank + 1), noise=0.1)    # D = X'Y + 0.1*N(0,1) on the device
+    if args.full_model:
+        # mu_j ~ N(0,1), logsigma_j ~ N(0,0.1); 2 views x 8 row batches (samples grouped by batch over the
+        # GLOBAL rows, each rank takes its slice), theta / logdelta = batch centre N(0,0.25^2) + N(0,0.25^2); 20 % Bernoulli
+        # columns (first in the column order: model.jl:50-54 sorts columns by distribution); 10 % missing
+        rng_m = np.random.default_rng(seed + 5)              # replicated: same numbers on every rank
+        ctx.set_col_params((0.1 * rng_m.standard_normal(N)).astype(np.float32), rng_m.standard_normal(N).astype(np.float32))
+        nb, half, views = 8, N // 2, []
+        for (s1, e1) in ((1, half), (half + 1, N)):
+            nv = e1 - s1 + 1
+            bor = np.sort(rng_m.integers(0, nb, M)).astype(np.int32)[lo:hi]
+            cd, ct = 0.25 * rng_m.standard_normal((nb, 1)), 0.25 * rng_m.standard_normal((nb, 1))
+            views.append(dict(start1=s1, stop1=e1, batch_of_row=np.ascontiguousarray(bor),
+                              logdelta=(cd + 0.25 * rng_m.standard_normal((nb, nv))).astype(np.float32),
+                              theta=(ct + 0.25 * rng_m.standard_normal((nb, nv))).astype(np.float32)))
+        ctx.set_batch_views(views)
+        nbern = N // 5
+        ctx.set_noise([(1, nbern), (nbern + 1, N)], ["bernoulli", "normal"], np.ones(N, np.float32))
+        ctx.synth_data(seed=seed + 17 * (rank + 1), noise=0.1, frac_nan=0.1)
+    else:
+        ctx.set_col_params(np.zeros(N, np.float32), np.zeros(N, np.float32))
+        ctx.set_batch_views([])
+        ctx.set_noise([(1, N)], ["normal"], np.ones(N, np.float32))
+        ctx.synth_data(seed=seed + 17 * (rank + 1), noise=0.1)    # D = X'Y + 0.1*N(0,1) on the device
     ctx.set_factors(X0, Y0)
     # group regularizer on X: 32 contiguous sample-condition groups over the GLOBAL rows, clipped to the shard
     ng = 32
@@ -216,8 +239,11 @@ def main():
             "dtype": ("bf16x3 (split-bf16 products, f32 accumulation and elementwise" + (", D stored bf16)" if args.store == "bf16" else ")"))
                      if split_main else "f32",
             "data": "synthetic",
-            "config": {"workload": f"fit! epoch on synthetic {M}x{N} matrix (D stored as {args.store}), K={K}, Gaussian loss, "
-                                   f"group-reg X (32 groups) + featureset-ARD Y, {args.optimizer}; rows sharded over {world} GPU(s)",
+            "config": {"workload": f"fit! epoch on synthetic {M}x{N} matrix (D stored as {args.store}), K={K}, "
+                                   + ("20 % Bernoulli + 80 % Gaussian columns, column scale / shift, BatchArray scale / shift on 2 views x 8 "
+                                      "row batches, 10 % missing entries, " if args.full_model else "Gaussian loss, ")
+                                   + f"group-reg X (32 groups) + featureset-ARD Y, {args.optimizer}; rows sharded over {world} GPU(s)",
+                       "full_model": bool(args.full_model),
                        "M": M, "N": N, "K": K, "rows_per_gpu": Ml, "optimizer": args.optimizer, "lr": lr,
                        "parallelism": (f"row-shard x{world}, library RCCL all-reduce of grad(Y) in {n_chunks} column chunks "
                                        f"beside the data pass ({cinfo['reserved_cus']} CUs left to RCCL)") if world > 1 else "single GPU",
@@ -255,11 +281,11 @@ def main():
             tr = json.loads((ROOT / "profiles" / "traffic_latest.json").read_text())
             trk = None
             wl = tr["workload"]
-            if (wl["M"], wl["N"], wl["K"], wl["n_gpus"]) == (M, N, K, world) and args.store == "f32":
+            if (wl["M"], wl["N"], wl["K"], wl["n_gpus"]) == (M, N, K, world) and args.store == "f32" and not args.full_model:
                 trk = tr["split_bf16"] if split_main else tr
             c4 = tr.get("config4_shard")
-            if c4 and split_main and (c4["workload"]["M"], c4["workload"]["N"], c4["workload"]["K"], c4["workload"]["n_gpus"],
-                                      c4["workload"]["store"]) == (M, N, K, world, args.store):
+            if c4 and split_main and not args.full_model and (c4["workload"]["M"], c4["workload"]["N"], c4["workload"]["K"], c4["workload"]["n_gpus"],
+                                                              c4["workload"]["store"]) == (M, N, K, world, args.store):
                 trk = c4
             if trk is not None:
                 out["roofline"]["traffic"] = trk["hbm_read_bytes_per_launch"] + trk["hbm_write_bytes_per_launch"]
