@@ -1,7 +1,10 @@
 """Randomised parity sweep: HIP path vs the fp64 oracle on random shapes / models (development aid, GPU box).
 python scripts/fuzz_parity.py [n_cases] [seed] [split]
-"split" draws the cases from the scope of the opt-in split-bf16 kernel (K <= 64, at most 15 batches per view; both gradients,
-grad(X) only or grad(Y) only), selects it with pmf_set_precision and checks that it was the kernel launched."""
+"split" selects the opt-in split-bf16 pass (pmf_set_precision), draws K from its scope (1..64 and 97..128; 65..96 stay on the
+exact kernel), both gradients / grad(X) only / grad(Y) only, and checks that the split kernel was the one launched whenever the
+launch is in its scope (the per-entry gather variant of the batch layers, bmode 2, is not).
+Round 2: views with up to 100 batches in sorted / scrambled / mixed row order, D stored as bf16 (the oracle is fed the
+rounded matrix), the layer pass with wide batch tables."""
 import sys
 from pathlib import Path
 import numpy as np
@@ -23,33 +26,40 @@ for c in range(n_cases):
     M = int(rng.choice([1, 3, 31, 32, 33, 255, 256, 257, 600, 1500, 5000, 20000, 70000]))
     N = int(rng.choice([1, 5, 31, 32, 33, 63, 64, 65, 200, 777, 2500]))
     if SPLIT:
-        K = int(rng.integers(1, 65))
+        K = int(rng.integers(1, 65)) if rng.random() < 0.7 else int(rng.integers(97, 129))
     if M * N * max(K, 8) > 6e8:   # keep the fp64 oracle in seconds
         N = int(rng.choice([33, 64, 100, 257]))
     nv = int(rng.integers(1, 4))
     bv = int(rng.integers(0, nv + 1)) if N >= 3 * nv else 0
-    nb = int(rng.choice([1, 2, 4, 9, 15, 16, 23]))
-    if SPLIT and nb > 15:
-        nb = 15       # (more batches per view than the dense LDS table holds: the exact kernel's gather path)
+    nb = int(rng.choice([1, 2, 4, 9, 15, 16, 23, 40, 100]))
+    order = str(rng.choice(["mixed", "sorted", "random"]))
+    store = "bf16" if rng.random() < 0.3 else "f32"
     bern = float(rng.choice([0.0, 0.0, 0.3, 1.0]))
     pois = float(rng.choice([0.0, 0.0, 0.2])) if bern < 1.0 else 0.0
     kw = dict(M=M, N=N, K=K, n_views=min(nv, N), batch_views=min(bv, N), n_batches=min(nb, max(M, 1)),
               bernoulli_frac=bern, poisson_frac=pois, nan_frac=float(rng.choice([0.0, 0.0, 0.05, 0.5])),
               weights=bool(rng.integers(0, 2)), col_params=bool(rng.integers(0, 2)), scale=0.4,
-              xreg=rng.choice([None, "l2", "group"]), yreg=rng.choice([None, "fsard", "ard", "group"]))
+              xreg=rng.choice([None, "l2", "group"]), yreg=rng.choice([None, "fsard", "ard", "group"]), batch_order=order)
     try:
         p = make_problem(seed=int(rng.integers(1 << 30)), **kw)
     except Exception as e:   # a shape the generator itself cannot build (e.g. more batches than rows)
         print(f"case {c}: generator skipped {kw}: {e}")
         continue
+    if store == "bf16":   # the device rounds D to bf16 at upload: the oracle gets the same matrix
+        u = np.ascontiguousarray(p["D"], dtype=np.float32).view(np.uint32).astype(np.uint64)
+        r = (((u + 0x7FFF + ((u >> 16) & 1)) >> 16) << 16).astype(np.uint32).view(np.float32).reshape(p["D"].shape)
+        p["D"] = np.asfortranarray(np.where(np.isnan(p["D"]), np.float32(np.nan), r).astype(np.float32))
     to_context(p, ctx)
+    if store == "bf16":
+        ctx.set_data(p["D"], store="bf16")
     mode = int(rng.integers(0, 3)) if SPLIT else 0          # 0 both gradients, 1 grad(X) only, 2 grad(Y) only
     ux, uy = mode != 2, mode != 1
     o = ctx.make_opts(update_X=ux, update_Y=uy)
     n_split0 = ctx.get_precision()[1]
     ctx.epoch_begin(o)
     loss, _ = ctx.epoch_loss()
-    if SPLIT and ctx.get_precision()[1] != n_split0 + 1:
+    in_scope = (K <= 64 or K > 96) and ctx.last_path()["bmode"] != 2
+    if SPLIT and in_scope and ctx.get_precision()[1] != n_split0 + 1:
         print(f"case {c}: FAIL the split-bf16 kernel was not launched for {kw}")
     gx, gy = (ctx.get_grad("X") if ux else None), (ctx.get_grad("Y") if uy else None)
     m = to_oracle(p)
@@ -70,6 +80,8 @@ for c in range(n_cases):
             el2 = max(el2, rel_err(ctx.get_grad("theta", v), g2["theta"][v]), rel_err(ctx.get_grad("logdelta", v), g2["logdelta"][v]))
     bad = el > 2e-5 or ex > 2e-4 or ey > 2e-4 or el2 > 2e-4 or not np.isfinite([el, ex, ey, el2]).all()
     worst = dict(loss=max(worst["loss"], el), gx=max(worst["gx"], ex), gy=max(worst["gy"], ey), layer=max(worst["layer"], el2))
-    print(f"case {c:3d} {'FAIL' if bad else 'ok  '} mode={mode} M={M} N={N} K={K} views={nv}/{bv} nb={nb} bern={bern} pois={pois} nan={kw['nan_frac']}: "
+    lp = ctx.last_path()
+    print(f"case {c:3d} {'FAIL' if bad else 'ok  '} mode={mode} M={M} N={N} K={K} views={nv}/{bv} nb={nb}/{order} store={store} bmode={lp['bmode']} lpath={lp['layer_path']} "
+          f"bern={bern} pois={pois} nan={kw['nan_frac']}: "
           f"loss {el:.1e} gX {ex:.1e} gY {ey:.1e} layers {el2:.1e}", flush=True)
 print("worst:", worst)
