@@ -33,6 +33,11 @@ class PathMatFacModel:  # model.jl:6-28
             self._ctx_data_id = key
         return self._ctx
 
+    def invalidate_device_data(self):
+        """Call after editing model.data IN PLACE: the HBM copy is keyed on the array's identity and shape, so an in-place
+        edit is not seen; the next device_context() uploads the matrix again."""
+        self._ctx_data_id = None
+
     def release_device(self):
         if self._ctx is not None:
             self._ctx.close()

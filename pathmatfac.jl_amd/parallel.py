@@ -99,7 +99,7 @@ def fit_distributed(ctx, dist=None, group=None, update_X=False, update_Y=False, 
             which = None
             if abs(diff) < abs_tol:
                 which = TERM_ABS_TOL
-            elif abs(diff / loss) < rel_tol:
+            elif (abs(diff / loss) if loss != 0 else np.inf) < rel_tol:   # (loss == 0: the C loop's inf, no ZeroDivisionError)
                 which = TERM_REL_TOL
             if which is not None:
                 tol_iters += 1
