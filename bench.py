@@ -299,7 +299,10 @@ def main():
             ncores = int(po.get_lib(32).lib.o_num_threads())     # OpenMP threads the oracle actually used
             # the reference's own CPU-runnable case (configs[0]) and configs[1], whole, on the same cores
             extra = {}
-            for tag, (m0, n0, k0, ep0) in (("configs[0] 500x200 K=4", (500, 200, 4, 50)), ("configs[1] 20000x10000 K=32", (20000, 10000, 32, 2))):
+            other_cfgs = (("configs[0] 500x200 K=4", (500, 200, 4, 50)), ("configs[1] 20000x10000 K=32", (20000, 10000, 32, 2)))
+            if os.environ.get("PMF_BENCH_SKIP_OTHER_CPU") == "1":   # (tests of the output contract: keep the run short)
+                other_cfgs = ()
+            for tag, (m0, n0, k0, ep0) in other_cfgs:
                 te = cpu_baseline(n0, k0, m0, ep0, seed, args.optimizer, lr)
                 extra[tag] = {"value": 1.0 / te, "unit": "iters/s", "epochs_timed": ep0}
             out["cpu_baseline_other_configs"] = extra
