@@ -358,6 +358,8 @@ int pmf_launch_fused_sb2(PmfDynLds *cache, hipStream_t stream, const FusedArgs &
 int pmf_launch_fused_sb2_bf16(PmfDynLds *cache, hipStream_t stream, const FusedArgs &a, int grid, bool batch, bool mixed, bool want_gx, bool want_gy);
 int pmf_launch_fused_sb4_4(PmfDynLds *cache, hipStream_t stream, const FusedArgs &a, int grid, bool batch, bool mixed, bool want_gx, bool want_gy);
 int pmf_launch_fused_sb4_4_bf16(PmfDynLds *cache, hipStream_t stream, const FusedArgs &a, int grid, bool batch, bool mixed, bool want_gx, bool want_gy);
+int pmf_launch_fused_sb4_3(PmfDynLds *cache, hipStream_t stream, const FusedArgs &a, int grid, bool batch, bool mixed, bool want_gx, bool want_gy);
+int pmf_launch_fused_sb4_3_bf16(PmfDynLds *cache, hipStream_t stream, const FusedArgs &a, int grid, bool batch, bool mixed, bool want_gx, bool want_gy);
 int pmf_launch_sb4_split(hipStream_t stream, const Sb4SplitArgs &a);
 int pmf_launch_sb_split_1(hipStream_t stream, const SbSplitArgs &a);
 int pmf_launch_sb_split_2(hipStream_t stream, const SbSplitArgs &a);

@@ -1718,8 +1718,7 @@ static FusedGeom fused_geometry(pmf_ctx *c, bool want_gx, bool want_gy, bool all
     if (c->btd_ok && ensure_panel_slots(c, 32 * g.NW, &g.ps) == 0 && g.ps && g.ps->ok) g.bmode = 1;
   }
   const bool sb_batch_ok = c->n_bv == 0 || (g.bmode == 1 && c->n_bv <= sb_max_bv);
-  // (K in 65..96 keeps three K blocks in the parameter buffers: no split variant is built for that stride)
-  g.sb = c->precision == PMF_PREC_BF16X3 && c->KB != 3 && sb_batch_ok && (want_gx || want_gy) && !getenv("PMF_DEBUG_FLAGS");
+  g.sb = c->precision == PMF_PREC_BF16X3 && sb_batch_ok && (want_gx || want_gy) && !getenv("PMF_DEBUG_FLAGS");
   if (g.sb) g.RBW = 1;
   g.BM = 32 * g.NW * g.RBW;
   g.n_rp = (c->M + g.BM - 1) / g.BM;
@@ -1939,6 +1938,7 @@ static int launch_fused_chunk(pmf_ctx *c, const FusedGeom &g, int s, bool want_g
     const sb_fn fn = c->KB == 1 ? (d16 ? pmf_launch_fused_sb_1_bf16 : pmf_launch_fused_sb_1)
                    : c->KB == 2 ? (use_sb2 ? (d16 ? pmf_launch_fused_sb2_bf16 : pmf_launch_fused_sb2)
                                            : (d16 ? pmf_launch_fused_sb_2_bf16 : pmf_launch_fused_sb_2))
+                   : c->KB == 3 ? (d16 ? pmf_launch_fused_sb4_3_bf16 : pmf_launch_fused_sb4_3)
                                 : (d16 ? pmf_launch_fused_sb4_4_bf16 : pmf_launch_fused_sb4_4);
     rc = fn(&c->dyn_lds, c->stream, a, grid, batch, c->mixed, want_gx, want_gy);
     c->sb_launches += 1;

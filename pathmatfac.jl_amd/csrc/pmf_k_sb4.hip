@@ -1,7 +1,7 @@
 // pmf_k_sb4.hip -- pmf_fused_sb4_kernel (64 < K <= 128) for one K-block count and one storage type of D
 // (-DPMF_KB=4 -DPMF_DB=0|1), k_sb4_split, and their launchers.
 #ifndef PMF_KB
-#error "compile with -DPMF_KB=4 -DPMF_DB=<0|1>"
+#error "compile with -DPMF_KB=<3|4> -DPMF_DB=<0|1>"
 #endif
 #ifndef PMF_DB
 #define PMF_DB 0
@@ -34,7 +34,7 @@ int PMF_SB4NAME(PMF_KB)(PmfDynLds *cache, hipStream_t stream, const FusedArgs &a
   return 0;
 }
 
-#if !PMF_DB
+#if !PMF_DB && PMF_KB == 4   // (one copy: see k_sb4_split)
 int pmf_launch_sb4_split(hipStream_t stream, const Sb4SplitArgs &a) {
   if (a.nblk <= 0) return 0;
   k_sb4_split<<<(unsigned)a.nblk, 256, 0, stream>>>(a);

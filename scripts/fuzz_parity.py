@@ -1,7 +1,6 @@
 """Randomised parity sweep: HIP path vs the fp64 oracle on random shapes / models (development aid, GPU box).
 python scripts/fuzz_parity.py [n_cases] [seed] [split]
-"split" selects the opt-in split-bf16 pass (pmf_set_precision), draws K from its scope (1..64 and 97..128; 65..96 stay on the
-exact kernel), both gradients / grad(X) only / grad(Y) only, and checks that the split kernel was the one launched whenever the
+"split" selects the opt-in split-bf16 pass (pmf_set_precision), draws K from 1..128, both gradients / grad(X) only / grad(Y) only, and checks that the split kernel was the one launched whenever the
 launch is in its scope (the per-entry gather variant of the batch layers, bmode 2, is not).
 Round 2: views with up to 100 batches in sorted / scrambled / mixed row order, D stored as bf16 (the oracle is fed the
 rounded matrix), the layer pass with wide batch tables."""
@@ -26,7 +25,7 @@ for c in range(n_cases):
     M = int(rng.choice([1, 3, 31, 32, 33, 255, 256, 257, 600, 1500, 5000, 20000, 70000]))
     N = int(rng.choice([1, 5, 31, 32, 33, 63, 64, 65, 200, 777, 2500]))
     if SPLIT:
-        K = int(rng.integers(1, 65)) if rng.random() < 0.7 else int(rng.integers(97, 129))
+        K = int(rng.integers(1, 65)) if rng.random() < 0.6 else int(rng.integers(65, 129))
     if M * N * max(K, 8) > 6e8:   # keep the fp64 oracle in seconds
         N = int(rng.choice([33, 64, 100, 257]))
     nv = int(rng.integers(1, 4))
@@ -58,7 +57,7 @@ for c in range(n_cases):
     n_split0 = ctx.get_precision()[1]
     ctx.epoch_begin(o)
     loss, _ = ctx.epoch_loss()
-    in_scope = (K <= 64 or K > 96) and ctx.last_path()["bmode"] != 2
+    in_scope = ctx.last_path()["bmode"] != 2
     if SPLIT and in_scope and ctx.get_precision()[1] != n_split0 + 1:
         print(f"case {c}: FAIL the split-bf16 kernel was not launched for {kw}")
     gx, gy = (ctx.get_grad("X") if ux else None), (ctx.get_grad("Y") if uy else None)

@@ -121,11 +121,11 @@ def test_split_bf16_agrees_with_exact_kernel_at_config_size(sctx):
 
 
 def test_split_bf16_falls_back_to_exact_kernel_outside_its_scope(sctx):
-    """64 < K <= 96 (three K blocks in the parameter buffers) and views with more than 15 batches (no dense LDS batch
-    table) have no split-bf16 variant: they must run the exact kernel (and say so through the launch counter), not fail."""
+    """A launch whose batch layers need the per-entry gather variant (a row panel that meets more than 15 batches of one
+    view) has no split-bf16 variant: it must run the exact kernel (and say so through the launch counter), not fail."""
     ctx, n0 = sctx
-    for case in (dict(M=200, N=150, K=90),
-                 dict(M=300, N=100, K=16, n_views=2, batch_views=2, n_batches=20, nan_frac=0.05, col_params=True)):
+    for case in (dict(M=300, N=100, K=16, n_views=2, batch_views=2, n_batches=20, nan_frac=0.05, col_params=True),
+                 dict(M=300, N=100, K=80, n_views=2, batch_views=2, n_batches=20, nan_frac=0.05, col_params=True)):
         p = make_problem(seed=11, **case)
         to_context(p, ctx)
         loss, g = grads_of(ctx, p, update_X=True, update_Y=True)
@@ -166,8 +166,13 @@ def test_split_bf16_headline_size_properties(sctx):
     assert ctx.get_precision()[1] == n0 + 4, "the split-bf16 kernel was not launched"
 
 
-# ---- 96 < K <= 128: pmf_fused_sb4_kernel (four waves, X operands in registers; csrc/pmf_fused_sb4.hip.inc) -------------
+# ---- 64 < K <= 128: pmf_fused_sb4_kernel (four waves, X operands in registers; csrc/pmf_fused_sb4.hip.inc) -------------
 CASES4 = {
+    # 64 < K <= 96: the three-K-block instantiation of the same kernel (96-factor parameter rows, 256-byte image rows)
+    "k65": dict(M=300, N=200, K=65, col_params=True, nan_frac=0.05),
+    "k80_mixed_batch": dict(M=420, N=260, K=80, bernoulli_frac=0.2, n_views=2, batch_views=2, n_batches=8, nan_frac=0.1,
+                            weights=True, col_params=True, scale=0.4),
+    "k96_many_panels": dict(M=40000, N=600, K=96, xreg="l2", weights=True, col_params=True, scale=0.3),
     "k100": dict(M=200, N=150, K=100, yreg="group", xreg="l2", col_params=True),
     "k128_nan": dict(M=140, N=65, K=128, nan_frac=0.05, col_params=True),
     "k128_ragged": dict(M=777, N=333, K=128, yreg="fsard", xreg="l2", nan_frac=0.1, weights=True, col_params=True, scale=0.4),
@@ -198,7 +203,7 @@ def test_split_bf16_k128_loss_and_gradients_match_oracle(sctx, name):
 
 
 @pytest.mark.parametrize("which", ["X", "Y"])
-@pytest.mark.parametrize("name", ["k128_ragged", "k112_batch"])
+@pytest.mark.parametrize("name", ["k128_ragged", "k112_batch", "k80_mixed_batch"])
 def test_split_bf16_k128_single_factor_gradient_matches_oracle(sctx, name, which):
     ctx, n0 = sctx
     p = make_problem(seed=13, **CASES4[name])
