@@ -275,8 +275,8 @@ int pmf_fsard_update_A(pmf_ctx *ctx, int64_t col_start1, int64_t col_stop1, int 
  *   PMF_PREC_F32    (default) exact f32 MFMA, v_mfma_f32_32x32x2_f32
  *   PMF_PREC_BF16X3 split-bf16: every f32 operand as a bf16 hi/lo pair, three bf16 MFMAs per product, f32 accumulation;
  *                   a six-term forward product as accurate as the f32 MFMA (2e-7 of max|Z|), three-term gradient products
- *                   (4e-6).  Used where a kernel variant exists (K <= 64, at most 15 batches per view); every other launch silently
- *                   stays exact.
+ *                   (4e-6).  Used where a kernel variant exists (every K <= 128; batch layers unless a 256-row panel meets more
+ *                   than 15 batches of one view, pmf_debug_last_path); every other launch silently stays exact.
  * pmf_get_precision also reports how many fused launches of this context took the split-bf16 kernel. */
 #define PMF_PREC_F32 0
 #define PMF_PREC_BF16X3 1
