@@ -260,7 +260,7 @@ def main():
                          "hbm_peak_GBps": 8000.0},
             "loss_first": losses[0], "loss_last": losses[-1],
         }
-        sb_name = "pmf_fused_sb_kernel" if K <= 64 else "pmf_fused_sb4_kernel"
+        sb_name = "pmf_fused_sb_kernel" if K <= 32 else ("pmf_fused_sb2_kernel" if K <= 64 else "pmf_fused_sb4_kernel")
         if split_main:
             # the split-bf16 kernel needs a quarter of the matrix cycles: what bounds it is the D stream
             d_gbps = dsz * Ml * N / n_chunks / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
