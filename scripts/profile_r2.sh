@@ -19,6 +19,11 @@ prof() {   # name, then the command's arguments (a python script with its argume
   echo "[$name] done: $(tail -1 $d/stats.log)"
 }
 B="--steps 4 --warmup 1 --no-cpu-baseline"
+if [ "${PMF_PROFILE_SET:-all}" = "full_model" ]; then   # the full-model flavours only (added late in round 2)
+  prof config4_shard_full "$ROOT/bench.py" $B --M 125000 --N 100000 --K 128 --precision bf16x3 --store bf16 --full-model
+  prof config2_full "$ROOT/bench.py" $B --M 20000 --N 10000 --K 32 --full-model
+  ls "$OUT"; exit 0
+fi
 prof headline "$ROOT/bench.py" $B
 prof config4_shard "$ROOT/bench.py" $B --M 125000 --N 100000 --K 128 --precision bf16x3 --store bf16
 prof config1 "$ROOT/bench.py" $B --M 20000 --N 10000 --K 32

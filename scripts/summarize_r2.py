@@ -18,7 +18,10 @@ WORK = {"headline": "python bench.py (200000 x 50000 f32, K = 64; exact kernel, 
         "config1": "python bench.py --M 20000 --N 10000 --K 32 (BASELINE configs[1])",
         "general": "scripts/kbench_mixed.py 100000 50000 64 all (20 % Bernoulli columns, 2 batch views x 8 batches, 5 % missing)",
         "layers": "scripts/kbench_layers.py 100000 50000 64 (layer-only epochs, then X + Y + layers epochs)",
-        "xonly_yonly": "scripts/kbench_xonly.py 100000 50000 64 (grad(X)-only, grad(Y)-only, both)"}
+        "xonly_yonly": "scripts/kbench_xonly.py 100000 50000 64 (grad(X)-only, grad(Y)-only, both)",
+        "config4_shard_full": "python bench.py --M 125000 --N 100000 --K 128 --precision bf16x3 --store bf16 --full-model (configs[4] shard: "
+                              "20 % Bernoulli columns, column + batch layers, 10 % missing)",
+        "config2_full": "python bench.py --M 20000 --N 10000 --K 32 --full-model (configs[2]: exact kernel, then the split-bf16 kernel)"}
 out_json = {}
 for name in sorted(p.name for p in src_root.iterdir() if p.is_dir()):
     src = src_root / name
