@@ -265,6 +265,15 @@ __device__ __forceinline__ float2 pmf_bt_entry(const FusedArgs &a, const unsigne
   return a.btd[pmf_bt_index(a, Pm, j + (e >> 4), e & 15, vw)];
 }
 
+// Workgroup b of a persistent grid of g -> its position in the work order.  Workgroups are dispatched to the 8 XCDs round
+// robin (b % 8); the workgroups of one XCD get CONSECUTIVE ranges of the work, so that they share column segments whose Y
+// tiles stay in that XCD's L2.  Any g: XCD x holds g/8 workgroups, the first g % 8 XCDs one more (a grid that leaves a few
+// CUs to RCCL is not a multiple of 8).
+__device__ __forceinline__ int pmf_xcd_wg(unsigned b, unsigned g) {
+  const unsigned x = b & 7, q = g >> 3, r = g & 7;
+  return (int)(x * q + (x < r ? x : r) + (b >> 3));
+}
+
 // ---- the data matrix tile in registers, f32 or bf16 storage
 // bf16 device layout of D (PMF_STORE_BF16): 32 x 32 tiles of 2 KiB in the same tile order as the f32 layout; inside a
 // tile 32-bit word q*256 + lane*4 + e holds accumulator registers 8q + 2e (low half) and 8q + 2e + 1 (high half) of

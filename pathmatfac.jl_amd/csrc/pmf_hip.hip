@@ -1723,7 +1723,9 @@ static FusedGeom fused_geometry(pmf_ctx *c, bool want_gx, bool want_gy, bool all
   g.BM = 32 * g.NW * g.RBW;
   g.n_rp = (c->M + g.BM - 1) / g.BM;
   g.n_ct_all = (c->N + PMF_BN - 1) / PMF_BN;
-  g.grid_max = std::max(1, c->n_cu - (c->comm.nranks > 1 ? c->comm.reserve_cus : 0));
+  int reserve = c->comm.nranks > 1 ? c->comm.reserve_cus : 0;
+  if (const char *e = getenv("PMF_RESERVE_CUS")) reserve = std::max(0, std::min(atoi(e), c->n_cu / 2));   // (tests / A-B: a one-rank run with the multi-rank grid)
+  g.grid_max = std::max(1, c->n_cu - reserve);
   int S = 1;
   if (allow_chunks && want_gy) {
     S = c->n_chunks_req > 0 ? c->n_chunks_req : 1;
