@@ -95,7 +95,10 @@ typedef struct pmf_fit_result {
 const char *pmf_last_error(void);
 int pmf_version(void);
 
-/* gpu(model) / cpu(model): analyses/scripts/julia/fit_matfac.jl:325-340, src/transform.jl:78-94 */
+/* gpu(model) / cpu(model): analyses/scripts/julia/fit_matfac.jl:325-340, src/transform.jl:78-94.
+ * pmf_device_count: HIP devices visible to this process (CUDA.device! / the per-process device choice of
+ * analyses/scripts/julia/script_util.jl:278-306): a launcher that pins one device per rank leaves ONE, device 0. */
+int pmf_device_count(int *n);
 int pmf_create(int device, pmf_ctx **out);
 int pmf_destroy(pmf_ctx *ctx);
 /* adopt an existing hipStream_t (e.g. the host framework's current stream); NULL = library-owned (non-blocking) stream.
@@ -204,14 +207,20 @@ int pmf_epoch_loss(pmf_ctx *ctx, double *local_loss, double *shared_terms);
  * steps of the replicated parameters and the same termination decision.  The step-level API below does not use the
  * communicator (there the host places its own collectives).
  *   pmf_comm_get_unique_id : ncclGetUniqueId; call on ONE rank, hand the PMF_COMM_ID_BYTES bytes to all (any side channel)
- *   pmf_comm_init          : ncclCommInitRank over RCCL / xGMI; collective over the ranks.  librccl.so.1 is loaded here
- *                            (dlopen), never before.  With nranks > 1 the data pass leaves PMF_COMM_CTAS CUs (env,
- *                            default 4) to the collective and NCCL_MAX_NCHANNELS is set to match unless already set.
+ *   pmf_comm_init          : ncclCommInitRank[Config] over RCCL / xGMI; collective over the ranks.  librccl.so.1 is loaded
+ *                            here (dlopen), never before.  With nranks > 1 the data pass leaves PMF_COMM_CTAS CUs (env,
+ *                            DEFAULT 4; 0 = none) to the collective's kernels, and this communicator alone is configured
+ *                            for as many workgroups (ncclConfig_t.maxCTAs): the library sets NO environment variable and
+ *                            touches nothing process-wide; other communicators of the host keep RCCL's defaults.
  *   pmf_comm_init_host     : the same protocol over a host callback `fn(user, host_buf, count, dtype)` that must sum
  *                            host_buf (dtype 0 = float32, 1 = float64) in place over the ranks and return 0; the library
  *                            stages device <-> pinned host memory around it.  For hosts without a usable RCCL ring
  *                            (tests: two ranks sharing one GPU).
- *   pmf_comm_set_chunks    : column chunks per data pass; 0 = automatic (1 on one rank, up to 4 with more)
+ *   pmf_comm_set_chunks    : column chunks per data pass; 0 = automatic (1 on one rank, up to 4 with more; chosen from N, K
+ *                            and the MEAN rows per rank, all-reduced once per pmf_fit, so that ranks with shards of
+ *                            different heights issue the same collectives).  A non-zero value must be the same on all ranks.
+ *   A pmf_fit that FAILS on a rank of a multi-rank communicator drains its streams and marks the communicator unusable
+ *   (the peers may be waiting in a collective it never issued): a rank failure is fatal for the group.
  *   pmf_comm_allreduce     : sum (op 0) / maximum (op 1) over the ranks of a HOST buffer (dtype 0 = float32, 1 = float64),
  *                            for what the host keeps between the GD stages: the statistics of pmf_stats that feed
  *                            init_logsigma! / reweight_col_losses! / theta_delta_em (src/fit.jl:125-187, 326-375) must be

@@ -752,6 +752,10 @@ int o_sizeof_real(void) { return (int)sizeof(real); }
 #ifdef _OPENMP
 #include <omp.h>
 int o_num_threads(void) { return omp_get_max_threads(); }
+/* bench.py's cpu_baseline leg sizes the team by the work (a 500 x 200 problem on 256 threads spends its time in the
+ * OpenMP barriers) and by the CPUs the process may actually use (cgroup quota), not by the host's thread count */
+void o_set_num_threads(int n) { omp_set_num_threads(n < 1 ? 1 : n); }
 #else
 int o_num_threads(void) { return 1; }
+void o_set_num_threads(int n) { (void)n; }
 #endif

@@ -40,7 +40,7 @@ class FitResult(C.Structure):
 
 # every symbol include/pmf_hip.h declares (checked by tests/test_abi.py against the header and the .so)
 EXPORTS = [
-    "pmf_last_error", "pmf_version", "pmf_create", "pmf_destroy", "pmf_set_stream", "pmf_synchronize",
+    "pmf_last_error", "pmf_version", "pmf_device_count", "pmf_create", "pmf_destroy", "pmf_set_stream", "pmf_synchronize",
     "pmf_set_data", "pmf_set_data_device", "pmf_set_factors", "pmf_set_X", "pmf_set_Y", "pmf_get_factors",
     "pmf_set_col_params", "pmf_get_col_params", "pmf_set_n_batch_views", "pmf_set_batch_view",
     "pmf_get_batch_view", "pmf_set_noise", "pmf_clear_xreg", "pmf_add_xreg_l2", "pmf_add_xreg_group",
@@ -64,6 +64,17 @@ def comm_unique_id(lib_path=None):
     if lib.pmf_comm_get_unique_id(buf) != 0:
         raise PMFError(lib.pmf_last_error().decode())
     return buf.raw
+
+
+
+def device_count(lib_path=None):
+    """HIP devices visible to this process (pmf_device_count)."""
+    lib = load_library(lib_path)
+    n = C.c_int(0)
+    if lib.pmf_device_count(C.byref(n)) != 0:
+        raise PMFError(lib.pmf_last_error().decode())
+    return n.value
+
 
 _lib = None
 

@@ -1,21 +1,6 @@
 // pmf_hip.hip -- libpmf_hip.so : MI355X (gfx950) implementation of PathMatFac's fit! loop behind the C ABI of
 // include/pmf_hip.h.  Written for CDNA4 only (wave64, v_mfma_f32_32x32x2_f32, 160 KiB LDS).
-#include <hip/hip_runtime.h>
-#include <rccl/rccl.h>   // types and enums only: the entry points are resolved with dlopen at pmf_comm_init (no link dependency)
-#include <dlfcn.h>
-
-#include <algorithm>
-#include <chrono>
-#include <cmath>
-#include <cstdarg>
-#include <cstdio>
-#include <cstdlib>
-#include <cstring>
-#include <string>
-#include <unordered_map>
-#include <vector>
-
-#include "pmf_common.h"
+#include "pmf_ctx.h"
 
 // ------------------------------------------------------------------------------------------------
 // error handling
@@ -33,154 +18,8 @@ int pmf_fail(const char *fmt, ...) {
 extern "C" const char *pmf_last_error(void) { return g_err.c_str(); }
 extern "C" int pmf_version(void) { return 1; }
 
-// ------------------------------------------------------------------------------------------------
-// context
-// ------------------------------------------------------------------------------------------------
-struct ParamBuf {  // one trainable parameter tensor with its gradient, optimizer state and quadratic regularizer
-  float *p = nullptr, *g = nullptr, *acc = nullptr, *mom = nullptr;
-  float *wq = nullptr, *cq = nullptr;  // dense quadratic weights / centres: 0.5*wq*(p-cq)^2 (nullptr = none)
-  int64_t n = 0;
-  float bp1 = 0.f, bp2 = 0.f;  // Adam running beta powers
-};
 
-// Panel-local batch slots.  The fused kernels look the batch parameters of (row, column) up in a 16-slot per-column table
-// in LDS.  With more than 15 batches in a view the slots are numbered PER ROW PANEL: slot s of (panel, view) is the s-th
-// distinct batch among the panel's rows (rows are normally sorted by batch: a 256-row panel holds a few), slot 15 the
-// identity.  pm[(rp * n_bv + v) * 16 + s] = that batch (255 = unused), row_slot[v * M + i] = the slot of row i.
-// ok = every (panel, view) has at most 15 distinct batches; otherwise the launch takes the gather fallback.
-struct PanelSlots {
-  int64_t serial = -1;
-  int BM = 0;
-  bool ok = false;
-  uint8_t *pm = nullptr, *row_slot = nullptr;
-};
-
-// Cached work split of one column chunk of the fused data pass (see compute_work_split).
-struct WorkSplit {
-  int64_t key[10] = {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1};
-  int grid = 0;
-  int64_t serial = 0;
-  int64_t *wg_begin = nullptr;     // [grid + 1] device: first work item of each workgroup
-  int32_t *c_off = nullptr, *c_idx = nullptr;   // per column tile of the chunk: the workgroups that visit it (CSR; k_gy_reduce)
-  int32_t *piece_base = nullptr;   // [grid] device: chunk-relative slot of each workgroup's first piece (gX partial buffer)
-  std::vector<int32_t> h_piece_base;
-  std::vector<int32_t> piece_rp;   // host: row panel of every piece, in slot order
-  int32_t slot_base = 0;           // first slot of this chunk in the flat gX partial buffer (set with the CSR)
-  int32_t *d_piece_base_abs = nullptr;   // [grid] device: piece_base + slot_base
-};
-
-// Cross-rank exchange of the sharded fit: rows are sharded, Y / column layers replicated; per epoch the
-// partial grad(Y) (and layer gradients, and the local loss) are summed over the ranks.  Two transports behind one
-// interface: RCCL (ncclAllReduce on a communication stream of the library's own, overlapped with the data pass), or a
-// host-staged callback (tests: two ranks sharing one GPU cannot form an RCCL ring).
-struct Comm {
-  int rank = 0, nranks = 1;
-  void *nccl = nullptr;            // ncclComm_t (RCCL transport)
-  pmf_host_allreduce_fn host_fn = nullptr;
-  void *host_user = nullptr;
-  hipStream_t stream = nullptr;    // communication stream
-  void *stage = nullptr;           // pinned staging buffer of the host-staged transport
-  size_t stage_bytes = 0;
-  int reserve_cus = 0;             // CUs left to the collective's kernels by the fused pass (RCCL transport)
-  std::vector<hipEvent_t> ev_ready, ev_done;   // per chunk: gY slice complete / its all-reduce complete
-  hipEvent_t ev_loss_ready = nullptr, ev_loss_done = nullptr, ev_layer_ready = nullptr, ev_layer_done = nullptr;
-  int64_t n_allreduce = 0;         // collectives issued (diagnostics / tests)
-};
-
-struct pmf_ctx {
-  int device = 0;
-  hipStream_t stream = nullptr;
-  bool own_stream = true;
-  int n_cu = 256;
-  int64_t M = 0, N = 0;
-  int K = 0, Kp = 0, KB = 0;
-  void *D = nullptr;   // tile-major copy of the data matrix, f32 (pmf_d_off) or bf16 (pmf_d_off16, `store`), always library-owned
-  bool own_D = false;
-  int64_t D_M = 0, D_Npad = 0, nRB = 0;
-  uint32_t *tflags = nullptr;     // per 32x32 tile of D: 1 = all 1024 entries finite (fast epilogue path of the fused kernel)
-  int64_t tflags_cap = 0;
-  bool tflags_valid = false;
-  int store = PMF_STORE_F32;
-  ParamBuf P[6];  // X, Y, logsigma, mu, logdelta, theta
-  // batch views
-  int n_bv = 0;
-  std::vector<ViewDesc> views;
-  std::vector<int64_t> val_off;  // per view offset into the flat logdelta/theta arrays
-  std::vector<int64_t> bvb_off;  // per view offset into the flat per-(view,batch) arrays
-  int32_t *bor = nullptr;
-  float2 *btab = nullptr;
-  bool views_dirty = true;        // `views` changed since the last upload
-  ViewDesc *d_views = nullptr;    // device copy of `views` for the fused kernel's global-gather fallback
-  float2 *LG = nullptr;           // [N][16] {S_G, S_Q} of the layer pass (pmf_layers.hip.inc)
-  int64_t LG_cap = 0;
-  float2 *btd = nullptr;          // dense per-column batch table [ceil(N/32)*32][nbs] (fused kernels, layer pass); see k_dense_btab
-  int64_t btd_cap = 0;
-  bool btd_ok = false;            // the dense table is built (every view has <= 255 batches)
-  int nbs = 16;                   // slots per column of the dense table: 16, or the power of two above the largest batch count
-  int64_t colview_cap = 0;
-  uint8_t *colview = nullptr;     // [ceil(N/32)*32] view of every column, 255 = none (k_dense_btab)
-  std::vector<std::vector<int32_t>> h_bor;   // host copy of batch_of_row per view (panel-local slot maps)
-  PanelSlots pslots[3];           // panel-local batch slots for row panels of 128 / 256 / 512 rows (ensure_panel_slots)
-  int64_t views_serial = 0;       // bumped whenever a view's rows / shape change
-  int last_bmode = 0, last_layer_path = 0;   // diagnostics (pmf_debug_last_path)
-  int32_t *d_val_view = nullptr;  // per flat value element: view id
-  // noise model / prepared column parameters
-  int32_t *colmeta = nullptr;  // kind | (view+1)<<2
-  float *colw = nullptr;
-  float4 *colp = nullptr;
-  bool mixed = false;
-  bool prepared = false;
-  // ARD-type regularizer on Y
-  float *ard_alpha = nullptr, *ard_beta = nullptr;
-  float ard_scale = 0.f;
-  bool has_ard = false;
-  // optimizer
-  int opt_kind = PMF_OPT_ADAGRAD;
-  float lr = 1.f, eps = 1e-8f, b1 = 0.9f, b2 = 0.999f;
-  bool state_init = false;
-  // loss plumbing
-  double *loss_partial = nullptr;
-  std::vector<uint8_t> h_kind;    // host copy of the per-column noise kind (cost model of the work split)
-  std::vector<WorkSplit> splits;  // cached work split of every column chunk of the fused pass (compute_work_split)
-  int n_chunks_req = 0;           // column chunks per data pass: 0 = automatic (1 on one GPU; pmf_comm_set_chunks)
-  float *gx_part = nullptr;       // [pieces][BM x Kp] per-piece partial sums of gX (fused kernel), summed by k_gx_reduce
-  size_t gx_part_cap = 0;         // floats
-  int32_t *gx_off = nullptr, *gx_idx = nullptr;   // per row panel: the slots of its pieces, in work-sequence order (CSR)
-  int64_t gx_serial = -1;         // sum of the splits' serials the CSR was built for
-  int64_t split_serial = 0;       // bumped whenever a split is recomputed
-  Comm comm;                      // cross-rank exchange (pmf_comm_init*); nranks == 1: none
-  int last_chunks = 1;            // column chunks of the last pmf_fit's data pass (pmf_comm_info)
-  hipEvent_t ev_host = nullptr;   // "the epoch's loss has reached the host" (pmf_fit)
-  int64_t kind_version = 0;
-  float *gy_slabs = nullptr;      // [grid][Kp x N] private per-workgroup gY partial sums of the fused kernel
-  size_t gy_slabs_cap = 0;        // floats
-  int precision = PMF_PREC_F32;   // products of the fused data pass: exact f32 MFMA, or split-bf16 (pmf_set_precision)
-  char *xsb = nullptr, *ysb = nullptr;   // split-bf16 operand images of X / sigma*Y, rebuilt every epoch (k_sb_split)
-  size_t xsb_cap = 0, ysb_cap = 0;       // bytes
-  int64_t sb_launches = 0;        // fused launches that took the split-bf16 kernel (pmf_get_precision)
-  int64_t loss_cap = 0;
-  int64_t n_macro = 0;
-  double *reg_partial = nullptr;  // [4][REG_SLOTS]
-  double *d_loss = nullptr;       // device [8]
-  double *h_loss = nullptr;       // pinned host [8]
-  // fused-kernel timing
-  std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
-  size_t ev_used = 0;
-  double kernel_ms_sum = 0.0;
-  int64_t kernel_launches = 0;
-  int reg_counts[4] = {0, 0, 0, 0};  // used slots of the regularizer partial slabs (0 X, 1 Y, 2 column layers)
-  // scratch
-  void *scratch = nullptr;
-  size_t scratch_bytes = 0;
-  // largest dynamic-LDS size set so far per kernel ON THIS CONTEXT'S DEVICE (hipFuncSetAttribute is per device: a
-  // process-wide cache would leave a second GPU's kernels without the attribute)
-  PmfDynLds dyn_lds;
-};
-
-#define REG_SLOTS 1024
-#define PMF_MAX_CHUNKS 16
-
-static int ctx_bind(pmf_ctx *c) {
+int ctx_bind(pmf_ctx *c) {
   if (!c) return pmf_fail("null context");
   HIPCHK(hipSetDevice(c->device));
   return 0;
@@ -190,26 +29,10 @@ static int ctx_bind(pmf_ctx *c) {
 // copies run on a NON-BLOCKING stream, which the NULL stream does not order.  Without the wait a later upload on the
 // library's stream can be overtaken by the fill (seen with two processes sharing one GPU: a regularizer's beta zeroed
 // after its upload).
-static int memset_now(void *p, int v, size_t bytes) {
+int memset_now(void *p, int v, size_t bytes) {
   HIPCHK(hipMemset(p, v, bytes));
   HIPCHK(hipStreamSynchronize(nullptr));
   return 0;
-}
-template <typename T>
-static int dev_alloc(T **p, size_t n, bool zero = true) {
-  if (*p) {
-    HIPCHK(hipFree(*p));
-    *p = nullptr;
-  }
-  if (n == 0) n = 1;
-  HIPCHK(hipMalloc((void **)p, n * sizeof(T)));
-  if (zero) PMFCHK(memset_now(*p, 0, n * sizeof(T)));
-  return 0;
-}
-template <typename T>
-static void dev_free(T **p) {
-  if (*p) (void)hipFree(*p);
-  *p = nullptr;
 }
 
 static int param_alloc(ParamBuf &b, int64_t n) {
@@ -234,7 +57,7 @@ int pmf_ensure_dyn_lds(PmfDynLds *cache, const void *kern, size_t lds) {
   (*cache)[kern] = lds;
   return 0;
 }
-static int ensure_dyn_lds(pmf_ctx *c, const void *kern, size_t lds) { return pmf_ensure_dyn_lds(&c->dyn_lds, kern, lds); }
+int ensure_dyn_lds(pmf_ctx *c, const void *kern, size_t lds) { return pmf_ensure_dyn_lds(&c->dyn_lds, kern, lds); }
 
 static int ensure_scratch(pmf_ctx *c, size_t bytes) {
   if (c->scratch_bytes >= bytes) return 0;
@@ -364,17 +187,6 @@ __device__ __forceinline__ float pmf_d_get(const void *D, int64_t i, int64_t j, 
   return reinterpret_cast<const float *>(D)[pmf_d_off(i, j, nRB)];
 }
 
-__device__ __forceinline__ double block_reduce_sum(double v, double *sh) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-  const int w = threadIdx.x >> 6;
-  if ((threadIdx.x & 63) == 0) sh[w] = v;
-  __syncthreads();
-  double s = 0.0;
-  if (threadIdx.x == 0)
-    for (int q = 0; q < (int)(blockDim.x >> 6); ++q) s += sh[q];
-  return s;  // valid on thread 0
-}
 
 struct StepArgs {
   float *p, *g, *acc, *mom;
@@ -441,7 +253,6 @@ __global__ __launch_bounds__(256) void k_reg_step(const StepArgs a) {
 }
 
 // fixed-order reduction of the loss partial slabs -> out[0..4]
-struct RegCounts { int c[4]; };
 __global__ __launch_bounds__(256) void k_loss_reduce(const double *data_partial, int64_t n_data, const double *reg_partial,
                                                      const RegCounts reg_counts, double *out, int mask) {
   __shared__ double sh[4];
@@ -455,6 +266,11 @@ __global__ __launch_bounds__(256) void k_loss_reduce(const double *data_partial,
     if (threadIdx.x == 0) out[which] = s;
     __syncthreads();
   }
+}
+int launch_loss_reduce(pmf_ctx *c, const RegCounts &rc, int mask) {
+  k_loss_reduce<<<1, 256, 0, c->stream>>>(c->loss_partial, c->n_macro, c->reg_partial, rc, c->d_loss, mask);
+  HIPCHK(hipGetLastError());
+  return 0;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -825,6 +641,14 @@ static int set_K(pmf_ctx *c, int K) {
   return 0;
 }
 
+extern "C" int pmf_device_count(int *n) {
+  if (!n) return pmf_fail("null output");
+  int ndev = 0;
+  HIPCHK(hipGetDeviceCount(&ndev));
+  *n = ndev;
+  return 0;
+}
+
 extern "C" int pmf_create(int device, pmf_ctx **out) {
   if (!out) return pmf_fail("null out");
   int ndev = 0;
@@ -852,7 +676,6 @@ extern "C" int pmf_create(int device, pmf_ctx **out) {
   return 0;
 }
 
-static int comm_release(pmf_ctx *c);
 extern "C" int pmf_destroy(pmf_ctx *c) {
   if (!c) return 0;
   (void)hipSetDevice(c->device);
@@ -1522,15 +1345,6 @@ __global__ __launch_bounds__(256) void k_gx_reduce(const float *__restrict__ par
   *reinterpret_cast<float4 *>(gX + e) = make_float4(a0.x + a1.x, a0.y + a1.y, a0.z + a1.z, a0.w + a1.w);
 }
 
-// Geometry of one fused data pass: kernel variant, row panels, column chunks.
-struct FusedGeom {
-  int NW = 8, RBW = 1, BM = 256, grid_max = 256, S = 1;
-  int bmode = 0;      // batch layers: 0 none, 1 LDS table with panel-local slots, 2 per-entry global gathers (fallback)
-  PanelSlots *ps = nullptr;
-  bool sb = false;    // split-bf16 products: pmf_fused_sb_kernel (K <= 64) or pmf_fused_sb4_kernel (64 < K <= 128)
-  int64_t n_rp = 0, n_ct_all = 0;
-  int64_t ct0[PMF_MAX_CHUNKS], nct[PMF_MAX_CHUNKS];
-};
 
 // Cost-balanced split of the fused kernel's work sequence for one column chunk (tiles [ct0, ct0 + n_ct); sequence =
 // segment-major, row panel, tile) into `grid` contiguous ranges.  A tile's estimated cost depends on the noise models of
@@ -1634,7 +1448,7 @@ extern "C" int pmf_debug_stamps(unsigned long long *out, int n) {
 }
 #endif
 
-static int harvest_events(pmf_ctx *c) {
+int harvest_events(pmf_ctx *c) {
   for (size_t e = 0; e < c->ev_used; ++e) {
     float ms = 0.f;
     if (hipEventElapsedTime(&ms, c->ev_pool[e].first, c->ev_pool[e].second) == hipSuccess) {
@@ -1701,7 +1515,7 @@ static int ensure_panel_slots(pmf_ctx *c, int BM, PanelSlots **out) {
 //   chunks: the column tiles are walked in S contiguous chunks, one launch each.  S = 1 unless the context has a
 //   communicator with more than one rank (then the all-reduce of chunk s's grad(Y) runs beside the launches of the later
 //   chunks and of the next epoch's earlier ones, pmf_fit) or pmf_comm_set_chunks asked for it.
-static FusedGeom fused_geometry(pmf_ctx *c, bool want_gx, bool want_gy, bool allow_chunks) {
+FusedGeom fused_geometry(pmf_ctx *c, bool want_gx, bool want_gy, bool allow_chunks) {
   FusedGeom g;
   const char *rbwenv = getenv("PMF_RBW");
   // (the batch-layer epilogue of two row blocks does not fit the 256-register budget: RBW = 2 spills and is 1.5x slower)
@@ -1739,14 +1553,19 @@ static FusedGeom fused_geometry(pmf_ctx *c, bool want_gx, bool want_gy, bool all
       // at these sizes, PMF_COMM_ALGBW_GBPS overrides) would not fit beside the rest of the pass.
       const char *bw = getenv("PMF_COMM_ALGBW_GBPS");
       const double algbw = (bw && atof(bw) > 0 ? atof(bw) : 60.0) * 1e9;
+      // Rank-invariant inputs only (every rank must choose the same S: it is the number and size of the collectives):
+      // N, Kp, the arithmetic mode and the MEAN rows per rank that pmf_fit has all-reduced (comm.m_mean), never the local
+      // row count or the kernel variant this rank's batch layout happens to allow.
+      const int64_t Mref = c->comm.m_mean > 0 ? c->comm.m_mean : c->M;
       const double bytes = 4.0 * (double)c->Kp * (double)c->N;
-      const double t_pass = 6.0 * (double)c->M * (double)c->N * (double)c->Kp / (g.sb ? 200e12 : 115e12);
+      const double t_pass = 6.0 * (double)Mref * (double)c->N * (double)c->Kp / (c->precision == PMF_PREC_BF16X3 ? 200e12 : 115e12);
       S = 2;
       while (S < 4 && 30e-6 + bytes / S / algbw > t_pass * (S - 1) / S) ++S;
+      // a chunk should give every workgroup a few dozen tiles at least (each launch pays its prologue and its tail)
+      const int64_t n_rp_ref = (Mref + g.BM - 1) / g.BM;
+      const int64_t min_tiles = 32ll * std::max(1, c->n_cu - c->comm.reserve_cus);
+      while (S > 1 && (n_rp_ref * g.n_ct_all) / S < min_tiles) --S;
     }
-    // a chunk should give every workgroup a few dozen tiles at least (each launch pays its prologue and its tail)
-    const int64_t min_tiles = 32ll * g.grid_max;
-    while (S > 1 && (g.n_rp * g.n_ct_all) / S < min_tiles && c->n_chunks_req <= 0) --S;
     S = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(S, PMF_MAX_CHUNKS), g.n_ct_all));
   }
   g.S = S;
@@ -1782,7 +1601,7 @@ static void chunk_segments(pmf_ctx *c, const FusedGeom &g, int s, int &grid, int
 }
 
 // Everything a data pass needs before its first launch: work splits of all chunks (cached), the gX slot map, buffers.
-static int prepare_fused_pass(pmf_ctx *c, const FusedGeom &g, bool want_gx, bool want_gy) {
+int prepare_fused_pass(pmf_ctx *c, const FusedGeom &g, bool want_gx, bool want_gy) {
   if ((int)c->splits.size() < g.S) c->splits.resize((size_t)g.S);
   int64_t grid_sum = 0, serial_sum = 0;
   for (int s = 0; s < g.S; ++s) {
@@ -1870,7 +1689,7 @@ static int sb_split_y(pmf_ctx *c, int64_t ct0, int64_t nct) {
 
 // One chunk of the data pass: the fused kernel over column tiles [ct0, ct0 + nct) and the fixed-order reduction of its
 // private gY slabs; after the LAST chunk, the fixed-order reduction of the gX partial slabs.
-static int launch_fused_chunk(pmf_ctx *c, const FusedGeom &g, int s, bool want_gx, bool want_gy) {
+int launch_fused_chunk(pmf_ctx *c, const FusedGeom &g, int s, bool want_gx, bool want_gy) {
   WorkSplit &ws = c->splits[(size_t)s];
   const int grid = ws.grid;
   int grid_dummy; int64_t tiles_per_seg, n_cseg;
@@ -2083,7 +1902,7 @@ static int launch_layer_pass(pmf_ctx *c, const pmf_fit_opts *o, bool with_loss) 
   return pmf_launch_layer_map(c->stream, m);
 }
 
-static int check_ready(pmf_ctx *c) {
+int check_ready(pmf_ctx *c) {
   if (!c->D) return pmf_fail("data not set");
   if (c->K == 0) return pmf_fail("factors not set");
   for (int v = 0; v < c->n_bv; ++v)
@@ -2095,7 +1914,7 @@ static int check_ready(pmf_ctx *c) {
 // e0 and n are multiples of Kp (whole columns): the pipelined loop of pmf_fit steps Y one column chunk at a time.
 // `max_blocks` bounds the grid (= loss partials appended to the slab); `advance` moves Adam's running beta powers on
 // (once per epoch, with the last slice).
-static int step_param_range(pmf_ctx *c, int which, int64_t e0, int64_t n, bool do_step, bool use_reg, int reg_slot,
+int step_param_range(pmf_ctx *c, int which, int64_t e0, int64_t n, bool do_step, bool use_reg, int reg_slot,
                             int *reg_count, int max_blocks, bool advance) {
   ParamBuf &b = c->P[which];
   if (b.n == 0 || n == 0) return 0;
@@ -2119,12 +1938,12 @@ static int step_param_range(pmf_ctx *c, int which, int64_t e0, int64_t n, bool d
   if (advance && do_step && c->opt_kind == PMF_OPT_ADAM) { b.bp1 *= c->b1; b.bp2 *= c->b2; }
   return 0;
 }
-static int step_param(pmf_ctx *c, int which, bool do_step, bool use_reg, int reg_slot, int *reg_count) {
+int step_param(pmf_ctx *c, int which, bool do_step, bool use_reg, int reg_slot, int *reg_count) {
   // the four layer parameters share one slab of loss partials: each gets a quarter (k_reg_step is grid-stride)
   return step_param_range(c, which, 0, c->P[which].n, do_step, use_reg, reg_slot, reg_count, reg_slot == 2 ? REG_SLOTS / 4 : REG_SLOTS, true);
 }
 // layer l <-> param: 1 logsigma(2), 2 logdelta(4), 3 mu(3), 4 theta(5)
-static int step_layers(pmf_ctx *c, const pmf_fit_opts *o, int *reg_count) {
+int step_layers(pmf_ctx *c, const pmf_fit_opts *o, int *reg_count) {
   const int fl = o->frozen_layers, fr = o->frozen_regs;
   const int pmap[4] = {2, 4, 3, 5};
   for (int l = 0; l < 4; ++l) {
@@ -2138,7 +1957,7 @@ static int step_layers(pmf_ctx *c, const pmf_fit_opts *o, int *reg_count) {
 }
 
 // what every epoch starts with: optimizer state, prepared column / batch tables, cleared layer gradients
-static int epoch_open(pmf_ctx *c, const pmf_fit_opts *o) {
+int epoch_open(pmf_ctx *c, const pmf_fit_opts *o) {
   if (!c->state_init) PMFCHK(init_opt_state(c));
   if (!c->prepared || o->update_col_layers) PMFCHK(prepare(c));
   // (grad(X) and grad(Y) need no clearing: k_gx_reduce / k_gy_reduce overwrite every element)
@@ -2147,7 +1966,7 @@ static int epoch_open(pmf_ctx *c, const pmf_fit_opts *o) {
       if (c->P[w].n) HIPCHK(hipMemsetAsync(c->P[w].g, 0, sizeof(float) * (size_t)c->P[w].n, c->stream));
   return 0;
 }
-static int epoch_layer_pass(pmf_ctx *c, const pmf_fit_opts *o, bool with_loss) {
+int epoch_layer_pass(pmf_ctx *c, const pmf_fit_opts *o, bool with_loss) {
   if (layer_pass_eligible(c)) { c->last_layer_path = 1; return launch_layer_pass(c, o, with_loss); }
   c->last_layer_path = 2;
   return launch_layer_grad(c, o, with_loss);
@@ -2193,8 +2012,7 @@ extern "C" int pmf_epoch_loss(pmf_ctx *c, double *local_loss, double *shared_ter
   PMFCHK(ctx_bind(c));
   RegCounts rc;
   for (int q = 0; q < 4; ++q) rc.c[q] = c->reg_counts[q];
-  k_loss_reduce<<<1, 256, 0, c->stream>>>(c->loss_partial, c->n_macro, c->reg_partial, rc, c->d_loss, 0x1f);
-  HIPCHK(hipGetLastError());
+  PMFCHK(launch_loss_reduce(c, rc, 0x1f));
   HIPCHK(hipMemcpyAsync(c->h_loss, c->d_loss, sizeof(double) * 5, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));
   harvest_events(c);
@@ -2204,405 +2022,6 @@ extern "C" int pmf_epoch_loss(pmf_ctx *c, double *local_loss, double *shared_ter
   return 0;
 }
 
-// ------------------------------------------------------------------------------------------------
-// cross-rank exchange (no reference counterpart: the reference is single-GPU, one process per GPU being its
-// habit for independent fits, analyses/scripts/julia/script_util.jl:278-306)
-// ------------------------------------------------------------------------------------------------
-struct RcclApi {
-  void *dl = nullptr;
-  ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
-  ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
-  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
-  ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
-  ncclResult_t (*GroupStart)() = nullptr;
-  ncclResult_t (*GroupEnd)() = nullptr;
-  const char *(*GetErrorString)(ncclResult_t) = nullptr;
-  const char *(*GetLastError)(ncclComm_t) = nullptr;
-};
-static RcclApi g_rccl;
-// RCCL is loaded on first use (dlopen): a single-GPU host never maps the 570 MB library, and libpmf_hip.so has no
-// link-time dependency on it.  librccl.so.1 resolves to the ROCm installation the library's own HIP runtime comes from.
-static int rccl_load() {
-  if (g_rccl.dl) return 0;
-  // The RCCL that belongs to THIS library's HIP runtime: the librccl.so.1 next to the libamdhip64 our HIP calls are bound
-  // to.  (A process that also holds PyTorch-ROCm has a second HIP runtime and a second RCCL, torch's bundled ones; a
-  // stream of one runtime must not reach the other's RCCL.)  PMF_RCCL_LIB overrides; plain names are the fallback.
-  std::string sibling;
-  {
-    Dl_info info;
-    if (dladdr((void *)&hipStreamCreateWithFlags, &info) && info.dli_fname) {
-      std::string p(info.dli_fname);
-      const size_t k = p.rfind('/');
-      if (k != std::string::npos) sibling = p.substr(0, k + 1) + "librccl.so.1";
-    }
-  }
-  const char *names[] = {getenv("PMF_RCCL_LIB"), sibling.empty() ? nullptr : sibling.c_str(), "librccl.so.1", "librccl.so"};
-  void *dl = nullptr;
-  for (const char *nm : names) {
-    if (!nm || !*nm) continue;
-    dl = dlopen(nm, RTLD_NOW | RTLD_LOCAL);
-    if (dl) break;
-  }
-  if (!dl) return pmf_fail("cannot load librccl.so.1 (%s): multi-GPU fits need RCCL", dlerror());
-  RcclApi r;
-  r.dl = dl;
-#define PMF_SYM(field, name)                                                          \
-  *(void **)(&r.field) = dlsym(dl, name);                                             \
-  if (!r.field) return pmf_fail("librccl: symbol %s not found", name)
-  PMF_SYM(GetUniqueId, "ncclGetUniqueId");
-  PMF_SYM(CommInitRank, "ncclCommInitRank");
-  PMF_SYM(CommDestroy, "ncclCommDestroy");
-  PMF_SYM(AllReduce, "ncclAllReduce");
-  PMF_SYM(GroupStart, "ncclGroupStart");
-  PMF_SYM(GroupEnd, "ncclGroupEnd");
-  PMF_SYM(GetErrorString, "ncclGetErrorString");
-#undef PMF_SYM
-  *(void **)(&r.GetLastError) = dlsym(dl, "ncclGetLastError");
-  g_rccl = r;
-  return 0;
-}
-static int rccl_chk(ncclResult_t rc, const char *what, ncclComm_t comm = nullptr) {
-  if (rc == ncclSuccess) return 0;
-  const char *detail = (g_rccl.GetLastError && comm) ? g_rccl.GetLastError(comm) : "";
-  return pmf_fail("%s failed: %s %s", what, g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "?", detail ? detail : "");
-}
-
-extern "C" int pmf_comm_get_unique_id(void *id_out) {
-  if (!id_out) return pmf_fail("null id buffer");
-  PMFCHK(rccl_load());
-  ncclUniqueId id;
-  PMFCHK(rccl_chk(g_rccl.GetUniqueId(&id), "ncclGetUniqueId"));
-  static_assert(sizeof(ncclUniqueId) == PMF_COMM_ID_BYTES, "ncclUniqueId size");
-  memcpy(id_out, &id, sizeof(id));
-  return 0;
-}
-
-static bool comm_active(const pmf_ctx *c) { return c->comm.nccl != nullptr || c->comm.host_fn != nullptr; }
-
-static int comm_release(pmf_ctx *c) {
-  Comm &m = c->comm;
-  if (m.stream) (void)hipStreamSynchronize(m.stream);
-  if (m.nccl && g_rccl.CommDestroy) (void)g_rccl.CommDestroy((ncclComm_t)m.nccl);
-  m.nccl = nullptr;
-  m.host_fn = nullptr;
-  m.host_user = nullptr;
-  for (auto e : m.ev_ready) (void)hipEventDestroy(e);
-  for (auto e : m.ev_done) (void)hipEventDestroy(e);
-  m.ev_ready.clear(); m.ev_done.clear();
-  hipEvent_t *evs[4] = {&m.ev_loss_ready, &m.ev_loss_done, &m.ev_layer_ready, &m.ev_layer_done};
-  for (auto pe : evs) { if (*pe) (void)hipEventDestroy(*pe); *pe = nullptr; }
-  if (m.stream) (void)hipStreamDestroy(m.stream);
-  m.stream = nullptr;
-  if (m.stage) (void)hipHostFree(m.stage);
-  m.stage = nullptr; m.stage_bytes = 0;
-  m.rank = 0; m.nranks = 1; m.reserve_cus = 0;
-  return 0;
-}
-static int comm_common_init(pmf_ctx *c, int rank, int nranks) {
-  if (nranks < 1 || rank < 0 || rank >= nranks) return pmf_fail("bad rank %d of %d", rank, nranks);
-  comm_release(c);
-  Comm &m = c->comm;
-  m.rank = rank; m.nranks = nranks;
-  HIPCHK(hipStreamCreateWithFlags(&m.stream, hipStreamNonBlocking));
-  hipEvent_t *evs[4] = {&m.ev_loss_ready, &m.ev_loss_done, &m.ev_layer_ready, &m.ev_layer_done};
-  for (auto pe : evs) HIPCHK(hipEventCreateWithFlags(pe, hipEventDisableTiming));
-  return 0;
-}
-
-extern "C" int pmf_comm_init(pmf_ctx *c, int rank, int nranks, const void *unique_id) {
-  PMFCHK(ctx_bind(c));
-  if (!unique_id) return pmf_fail("null unique id");
-  PMFCHK(rccl_load());
-  // The fused pass is a persistent grid that fills every CU: a collective's kernels get a CU only when a workgroup
-  // retires.  With more than one rank the pass therefore leaves PMF_COMM_CTAS CUs (default 4) free and RCCL is held to
-  // as many channels (one workgroup each); 0 = no reservation, RCCL's own channel count.
-  int ctas = 4;
-  if (const char *e = getenv("PMF_COMM_CTAS")) ctas = atoi(e);
-  if (nranks > 1 && ctas > 0) {
-    char buf[16];
-    snprintf(buf, sizeof(buf), "%d", ctas);
-    setenv("NCCL_MAX_NCHANNELS", buf, 0);   // (not overwritten when the host has set it)
-  }
-  PMFCHK(comm_common_init(c, rank, nranks));
-  ncclUniqueId id;
-  memcpy(&id, unique_id, sizeof(id));
-  ncclComm_t comm = nullptr;
-  const int rc = rccl_chk(g_rccl.CommInitRank(&comm, nranks, id, rank), "ncclCommInitRank");
-  if (rc < 0) { comm_release(c); return rc; }
-  c->comm.nccl = comm;
-  c->comm.reserve_cus = nranks > 1 ? std::max(0, std::min(ctas, c->n_cu / 4)) : 0;
-  return 0;
-}
-
-extern "C" int pmf_comm_init_host(pmf_ctx *c, int rank, int nranks, pmf_host_allreduce_fn fn, void *user) {
-  PMFCHK(ctx_bind(c));
-  if (!fn) return pmf_fail("null all-reduce callback");
-  PMFCHK(comm_common_init(c, rank, nranks));
-  c->comm.host_fn = fn;
-  c->comm.host_user = user;
-  return 0;
-}
-
-extern "C" int pmf_comm_destroy(pmf_ctx *c) {
-  PMFCHK(ctx_bind(c));
-  return comm_release(c);
-}
-
-extern "C" int pmf_comm_set_chunks(pmf_ctx *c, int n_chunks) {
-  if (!c) return pmf_fail("null context");
-  if (n_chunks < 0 || n_chunks > PMF_MAX_CHUNKS) return pmf_fail("n_chunks=%d out of range (0..%d)", n_chunks, PMF_MAX_CHUNKS);
-  c->n_chunks_req = n_chunks;
-  return 0;
-}
-
-extern "C" int pmf_comm_info(pmf_ctx *c, int *rank, int *nranks, int *transport, int *n_chunks, int *reserved_cus,
-                             int64_t *n_collectives) {
-  if (!c) return pmf_fail("null context");
-  if (rank) *rank = c->comm.rank;
-  if (nranks) *nranks = c->comm.nranks;
-  if (transport) *transport = c->comm.nccl ? PMF_COMM_RCCL : (c->comm.host_fn ? PMF_COMM_HOST : PMF_COMM_NONE);
-  if (n_chunks) *n_chunks = c->last_chunks;
-  if (reserved_cus) *reserved_cus = c->comm.nranks > 1 ? c->comm.reserve_cus : 0;
-  if (n_collectives) *n_collectives = c->comm.n_allreduce;
-  return 0;
-}
-
-// in-place sum over the ranks of `count` elements at device address p, ordered on the communication stream
-static int comm_allreduce(pmf_ctx *c, void *p, int64_t count, bool f64) {
-  Comm &m = c->comm;
-  if (count <= 0) return 0;
-  m.n_allreduce++;
-  if (m.nccl)
-    return rccl_chk(g_rccl.AllReduce(p, p, (size_t)count, f64 ? ncclFloat64 : ncclFloat32, ncclSum, (ncclComm_t)m.nccl, m.stream),
-                    "ncclAllReduce", (ncclComm_t)m.nccl);
-  // host-staged transport (tests): device -> pinned host -> callback (e.g. gloo) -> device, blocking
-  const size_t bytes = (size_t)count * (f64 ? 8 : 4);
-  if (bytes > m.stage_bytes) {
-    if (m.stage) (void)hipHostFree(m.stage);
-    m.stage = nullptr; m.stage_bytes = 0;
-    HIPCHK(hipHostMalloc(&m.stage, bytes));
-    m.stage_bytes = bytes;
-  }
-  HIPCHK(hipMemcpyAsync(m.stage, p, bytes, hipMemcpyDeviceToHost, m.stream));
-  HIPCHK(hipStreamSynchronize(m.stream));
-  if (m.host_fn(m.host_user, m.stage, count, f64 ? 1 : 0) != 0) return pmf_fail("host all-reduce callback failed");
-  HIPCHK(hipMemcpyAsync(p, m.stage, bytes, hipMemcpyHostToDevice, m.stream));
-  HIPCHK(hipStreamSynchronize(m.stream));
-  return 0;
-}
-// Sum (op 0) or maximum (op 1) over the ranks of a HOST buffer through the communicator, for what the host keeps
-// between the GD stages: the column / batch statistics of pmf_stats, timings, flags.  Blocking.
-extern "C" int pmf_comm_allreduce(pmf_ctx *c, void *host_buf, int64_t count, int dtype, int op) {
-  PMFCHK(ctx_bind(c));
-  if (!host_buf || count < 0) return pmf_fail("bad buffer");
-  if (dtype != 0 && dtype != 1) return pmf_fail("dtype must be 0 (float32) or 1 (float64)");
-  if (op != 0 && op != 1) return pmf_fail("op must be 0 (sum) or 1 (max)");
-  if (!comm_active(c) || count == 0) return 0;   // one rank: nothing to do
-  Comm &m = c->comm;
-  const size_t bytes = (size_t)count * (dtype ? 8 : 4);
-  if (m.nccl) {
-    void *d = nullptr;
-    HIPCHK(hipMalloc(&d, bytes));
-    hipError_t e = hipMemcpyAsync(d, host_buf, bytes, hipMemcpyHostToDevice, m.stream);
-    int rc = 0;
-    if (e == hipSuccess)
-      rc = rccl_chk(g_rccl.AllReduce(d, d, (size_t)count, dtype ? ncclFloat64 : ncclFloat32, op ? ncclMax : ncclSum, (ncclComm_t)m.nccl, m.stream),
-                    "ncclAllReduce", (ncclComm_t)m.nccl);
-    if (e == hipSuccess && rc == 0) e = hipMemcpyAsync(host_buf, d, bytes, hipMemcpyDeviceToHost, m.stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(m.stream);
-    (void)hipFree(d);
-    if (rc < 0) return rc;
-    if (e != hipSuccess) return pmf_fail("pmf_comm_allreduce: %s", hipGetErrorString(e));
-    m.n_allreduce++;
-    return 0;
-  }
-  if (op != 0) return pmf_fail("the host-staged transport only sums");
-  if (m.host_fn(m.host_user, host_buf, count, dtype) != 0) return pmf_fail("host all-reduce callback failed");
-  m.n_allreduce++;
-  return 0;
-}
-
-// the communication stream continues after everything enqueued on the compute stream so far / vice versa
-static int comm_after_compute(pmf_ctx *c, hipEvent_t ev) {
-  HIPCHK(hipEventRecord(ev, c->stream));
-  HIPCHK(hipStreamWaitEvent(c->comm.stream, ev, 0));
-  return 0;
-}
-static int comm_mark(pmf_ctx *c, hipEvent_t ev) {
-  HIPCHK(hipEventRecord(ev, c->comm.stream));
-  return 0;
-}
-static int compute_after_comm(pmf_ctx *c, hipEvent_t ev) {
-  HIPCHK(hipStreamWaitEvent(c->stream, ev, 0));
-  return 0;
-}
-
-// MF.fit!(model.matfac, model.data; ...) (src/fit.jl:24-36): the epoch loop.
-//
-// One epoch = data pass (fused kernel over S column chunks [+ layer pass]) -> X step -> Y step per chunk [-> layer steps]
-// -> loss.  The loop is software-pipelined across epochs: the data pass of epoch e+1 is launched BEFORE the host has
-// seen the loss of epoch e -- chunk s of epoch e+1 right after the Y step of chunk s of epoch e, which is all it depends
-// on besides the X step -- so that
-//   * the host's wait for the loss (and its termination test) runs beside the next data pass instead of idling the GPU,
-//   * with a communicator, the all-reduce of chunk s's grad(Y) has until the Y step of chunk s to finish, i.e. it runs
-//     beside the launches of chunks s+1 .. S-1 of this epoch and 0 .. s-1 of the next: no collective sits on the
-//     critical path (one exchange step per epoch: S grad(Y) slices, the local loss as two doubles, and the layer
-//     gradients when they train).
-// A data pass only writes gradient buffers, never parameters: when epoch e terminates the fit, the speculative pass of
-// e+1 is simply dropped and the parameters are exactly those after epoch e's steps (same results as the plain loop).
-extern "C" int pmf_fit(pmf_ctx *c, const pmf_fit_opts *o, pmf_fit_result *res) {
-  PMFCHK(ctx_bind(c));
-  PMFCHK(check_ready(c));
-  if (!o || !res) return pmf_fail("null opts/result");
-  const auto t0 = std::chrono::steady_clock::now();
-  const bool ux = o->update_X != 0, uy = o->update_Y != 0, ul = o->update_col_layers != 0;
-  const bool fused = ux || uy || !ul;
-  const bool cm = comm_active(c);
-  // (the first epoch is opened before the geometry is chosen: prepare() decides whether the dense batch table exists,
-  //  which decides the kernel variant and with it the row-panel height)
-  if (o->epoch <= o->max_epochs) PMFCHK(epoch_open(c, o));
-  FusedGeom g;
-  if (fused) g = fused_geometry(c, ux, uy, /*allow_chunks=*/!ul);
-  const int S = fused ? g.S : 1;
-  c->last_chunks = S;
-  Comm &m = c->comm;
-  if (cm) {
-    while ((int)m.ev_ready.size() < S) {
-      hipEvent_t e0, e1;
-      HIPCHK(hipEventCreateWithFlags(&e0, hipEventDisableTiming));
-      HIPCHK(hipEventCreateWithFlags(&e1, hipEventDisableTiming));
-      m.ev_ready.push_back(e0);
-      m.ev_done.push_back(e1);
-    }
-  }
-  if (!c->ev_host) HIPCHK(hipEventCreateWithFlags(&c->ev_host, hipEventDisableTiming));
-  int term = PMF_TERM_MAX_EPOCHS, tol_iters = 0, n = 0, last_epoch = o->epoch - 1;
-  double prev = 0.0, loss = 0.0;
-  const int tol_max = o->tol_max_iters > 0 ? o->tol_max_iters : 3;
-
-  // chunk s of an epoch's data pass, with the exchange of what it completes
-  auto pass_chunk = [&](int s) -> int {
-    if (fused) {
-      PMFCHK(launch_fused_chunk(c, g, s, ux, uy));
-      if (cm && uy) {
-        const int64_t col0 = g.ct0[s] * 32, col1 = std::min<int64_t>(c->N, (g.ct0[s] + g.nct[s]) * 32);
-        PMFCHK(comm_after_compute(c, m.ev_ready[(size_t)s]));
-        PMFCHK(comm_allreduce(c, c->P[1].g + col0 * c->Kp, (col1 - col0) * c->Kp, false));
-        PMFCHK(comm_mark(c, m.ev_done[(size_t)s]));
-      }
-    }
-    if (ul && s == S - 1) {
-      PMFCHK(epoch_layer_pass(c, o, !fused));
-      if (cm) {
-        PMFCHK(comm_after_compute(c, m.ev_layer_ready));
-        if (m.nccl) PMFCHK(rccl_chk(g_rccl.GroupStart(), "ncclGroupStart"));
-        for (int w = 2; w < 6; ++w) PMFCHK(comm_allreduce(c, c->P[w].g, c->P[w].n, false));
-        if (m.nccl) PMFCHK(rccl_chk(g_rccl.GroupEnd(), "ncclGroupEnd", (ncclComm_t)m.nccl));
-        PMFCHK(comm_mark(c, m.ev_layer_done));
-      }
-    }
-    return 0;
-  };
-
-  bool in_flight = false;   // a data pass whose epoch has not been finished is enqueued
-  if (o->epoch <= o->max_epochs) {
-    if (fused) PMFCHK(prepare_fused_pass(c, g, ux, uy));
-    for (int s = 0; s < S; ++s) PMFCHK(pass_chunk(s));
-    in_flight = true;
-  }
-  for (int epoch = o->epoch; epoch <= o->max_epochs; ++epoch) {
-    const bool more = epoch < o->max_epochs;
-    RegCounts rc;
-    for (int q = 0; q < 4; ++q) rc.c[q] = 0;
-    // ---- X step (row-local) and the rank-local part of the loss: data term + X regularizer
-    if (ux) PMFCHK(step_param(c, 0, true, true, 0, &rc.c[0]));
-    k_loss_reduce<<<1, 256, 0, c->stream>>>(c->loss_partial, c->n_macro, c->reg_partial, rc, c->d_loss, 0x03);
-    HIPCHK(hipGetLastError());
-    if (cm) {
-      PMFCHK(comm_after_compute(c, m.ev_loss_ready));
-      PMFCHK(comm_allreduce(c, c->d_loss, 2, true));
-      PMFCHK(comm_mark(c, m.ev_loss_done));
-    }
-    in_flight = false;
-    // ---- replicated parameters, chunk by chunk; the next epoch's chunk follows its Y step
-    for (int s = 0; s < S; ++s) {
-      if (uy) {
-        if (cm) PMFCHK(compute_after_comm(c, m.ev_done[(size_t)s]));
-        const int64_t col0 = fused ? g.ct0[s] * 32 : 0;
-        const int64_t col1 = fused ? std::min<int64_t>(c->N, (g.ct0[s] + g.nct[s]) * 32) : c->N;
-        PMFCHK(step_param_range(c, 1, col0 * c->Kp, (col1 - col0) * c->Kp, true, true, 1, &rc.c[1], REG_SLOTS / S, s == S - 1));
-      }
-      if (s == S - 1) {
-        if (ul) {
-          if (cm) PMFCHK(compute_after_comm(c, m.ev_layer_done));
-          PMFCHK(step_layers(c, o, &rc.c[2]));
-        }
-        if (cm) PMFCHK(compute_after_comm(c, m.ev_loss_done));
-        k_loss_reduce<<<1, 256, 0, c->stream>>>(c->loss_partial, c->n_macro, c->reg_partial, rc, c->d_loss, 0x1c);
-        HIPCHK(hipGetLastError());
-        HIPCHK(hipMemcpyAsync(c->h_loss, c->d_loss, sizeof(double) * 5, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(hipEventRecord(c->ev_host, c->stream));
-      }
-      if (more) {
-        if (s == 0 && S > 1) PMFCHK(epoch_open(c, o));
-        if (s == S - 1 && S == 1) PMFCHK(epoch_open(c, o));
-        PMFCHK(pass_chunk(s));
-        in_flight = true;
-      }
-    }
-    HIPCHK(hipEventSynchronize(c->ev_host));
-    loss = c->h_loss[0] + c->h_loss[1] + (c->h_loss[2] + c->h_loss[3]);
-    if (getenv("PMF_DEBUG_LOSS"))
-      fprintf(stderr, "[pmf rank %d] epoch %d: data %.10g xreg %.10g yreg %.10g layers %.10g (n_macro %lld, reg counts %d %d %d)\n", m.rank, epoch,
-              c->h_loss[0], c->h_loss[1], c->h_loss[2], c->h_loss[3], (long long)c->n_macro, rc.c[0], rc.c[1], rc.c[2]);
-    if (getenv("PMF_DEBUG_LOSS") && !std::isfinite(c->h_loss[2])) {
-      HIPCHK(hipDeviceSynchronize());
-      auto dump = [&](const char *nm, const float *d, int64_t cnt) {
-        std::vector<float> h((size_t)cnt);
-        (void)hipMemcpy(h.data(), d, sizeof(float) * (size_t)cnt, hipMemcpyDeviceToHost);
-        double mn = 1e300, mx = -1e300; int64_t bad = 0, first = -1;
-        for (int64_t e = 0; e < cnt; ++e) { if (!std::isfinite(h[(size_t)e])) { if (first < 0) first = e; ++bad; } else { mn = std::min<double>(mn, h[(size_t)e]); mx = std::max<double>(mx, h[(size_t)e]); } }
-        fprintf(stderr, "[pmf rank %d]   %s: n %lld min %g max %g nonfinite %lld (first at %lld)\n", m.rank, nm, (long long)cnt, mn, mx, (long long)bad, (long long)first);
-      };
-      dump("Y", c->P[1].p, c->P[1].n); dump("gY", c->P[1].g, c->P[1].n); dump("accY", c->P[1].acc, c->P[1].n);
-      if (c->ard_beta) { dump("beta", c->ard_beta, c->P[1].n); dump("alpha", c->ard_alpha, c->N); }
-      std::vector<double> rp((size_t)rc.c[1]);
-      (void)hipMemcpy(rp.data(), c->reg_partial + REG_SLOTS, sizeof(double) * rp.size(), hipMemcpyDeviceToHost);
-      for (size_t q = 0; q < rp.size(); ++q) if (!std::isfinite(rp[q])) fprintf(stderr, "[pmf rank %d]   yreg partial %zu = %g\n", m.rank, q, rp[q]);
-    }
-    if (res->loss_trace && n < res->trace_cap) res->loss_trace[n] = loss;
-    ++n;
-    last_epoch = epoch;
-    if (o->verbosity > 0 && o->print_iter > 0 && (epoch % o->print_iter == 0))
-      fprintf(stderr, "(%d) Loss=%.8g\n", epoch, loss);
-    if (!std::isfinite(loss)) { term = PMF_TERM_NONFINITE; break; }
-    if (n > 1) {
-      const double diff = prev - loss;
-      if (diff < 0) { term = PMF_TERM_LOSS_INCREASE; break; }
-      int which = -1;
-      if (std::fabs(diff) < o->abs_tol) which = PMF_TERM_ABS_TOL;
-      else if (std::fabs(diff / loss) < o->rel_tol) which = PMF_TERM_REL_TOL;
-      if (which >= 0) {
-        if (++tol_iters >= tol_max) { term = which; break; }
-      } else {
-        tol_iters = 0;
-      }
-    }
-    prev = loss;
-  }
-  // a speculative data pass (and its collectives: every rank took the same decision on the same loss, so every rank
-  // enqueued them) may still be running: the call returns with both streams idle
-  (void)in_flight;
-  HIPCHK(hipStreamSynchronize(c->stream));
-  if (cm) HIPCHK(hipStreamSynchronize(m.stream));
-  harvest_events(c);
-  res->term_code = term;
-  res->epochs = last_epoch;
-  res->n_trace = res->loss_trace ? std::min(n, res->trace_cap) : 0;
-  res->final_loss = loss;
-  res->seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-  return 0;
-}
 
 extern "C" int pmf_grad_device_ptr(pmf_ctx *c, int which, void **ptr, int64_t *n) {
   PMFCHK(ctx_bind(c));
@@ -2653,271 +2072,6 @@ extern "C" int pmf_get_opt_state(pmf_ctx *c, int which, int view, float *acc, fl
 }
 
 
-// ------------------------------------------------------------------------------------------------
-// FeatureSetARD outer loop: update_A! (src/featureset_ard.jl:214-294) -- nonnegative projected ISTA with AdaGrad step
-// sizes (ISTAOptimiser, src/optimizers.jl:26-62) on the view's assignment matrix A (L feature sets x K factors),
-// minimising gamma_normal_loss(A) + sum_k lambda_k |A_lk| (src/featureset_ard.jl:154-162 and its rrule :164-186; the
-// primal of the rrule is never used for a value: update_A_inner! calls the plain function).  Up to max_epochs serial
-// iterations of two small kernels per view, no host round trip inside a batch of iterations:
-//   k_fsard_grad  : (column slices of the view) A'S, the loss at A, grad_{A'S}, partial S * grad' per workgroup
-//   k_fsard_step  : (one workgroup) fixed-order sum of the partials, loss bookkeeping exactly as update_A_inner!
-//                   (best loss, A_best, termination counter), then the ISTA update of A unless the loop has ended.
-// Y stays where the fit left it (the context's device copy); beta = beta0 (v0 + A'S) is written straight into the
-// Y regularizer's device array (featureset_ard.jl:292) as well as returned.
-// ------------------------------------------------------------------------------------------------
-struct FsardArgs {
-  const float *Y;          // context Y, Kp x N, column j at Y + j*Kp
-  const float *S;          // L x Nv row-major (feature set l's weights over the view's columns)
-  const float *alpha;      // Nv
-  const float *lambda;     // K
-  float *A, *A_best, *ssq; // L x K (k contiguous)
-  float *gpart;            // [n_wg][L*K] partial gradients
-  double *lpart;           // [n_wg] partial data losses
-  double *state;           // [0] best loss, [1] loss of the last evaluated A, [4] calibration constant (unused)
-  int32_t *istate;         // [0] done, [1] term_count, [2] evaluations so far, [3] max_epochs, [4] term_iter
-  float *beta_dev;         // ard_beta + c0*Kp (may be null)
-  int64_t c0, Nv;
-  int32_t L, K, Kp, CW, n_wg;
-  float alpha0, v0, lr;
-  double atol;
-};
-
-// thread = column (CW = blockDim.x columns per sub-slice); A in LDS; the sub-slice's grad_{A'S} tile [K][CW] in LDS;
-// then thread -> (l, k) outputs, each a dot product over the sub-slice.  final_beta != 0: only write beta (no gradient).
-__global__ __launch_bounds__(256) void k_fsard_grad(const FsardArgs a, int final_beta) {
-  extern __shared__ __attribute__((aligned(16))) char smem_fs[];
-  float *As = reinterpret_cast<float *>(smem_fs);      // [L][K]
-  float *Gt = As + a.L * a.K;                           // [K][CW + 1] (odd row stride: the dot products below read a column of rows)
-  const int GS = a.CW + 1;
-  __shared__ double sh[4];
-  if (!final_beta && a.istate[0]) return;               // the loop has ended: nothing left to evaluate
-  const int tid = threadIdx.x, NT = blockDim.x;
-  const float *Asrc = final_beta ? a.A_best : a.A;
-  for (int e = tid; e < a.L * a.K; e += NT) As[e] = Asrc[e];
-  const int64_t per = (a.Nv + a.n_wg - 1) / a.n_wg;
-  const int64_t j_lo = blockIdx.x * per, j_hi = j_lo + per < a.Nv ? j_lo + per : a.Nv;
-  const float beta0 = a.alpha0 - 1.f;
-  constexpr int MAXO = 64;                              // (l, k) outputs per thread: L*K <= 64 * 256
-  float gacc[MAXO];
-#pragma unroll
-  for (int o = 0; o < MAXO; ++o) gacc[o] = 0.f;
-  double lacc = 0.0;
-  __syncthreads();
-  for (int64_t js = j_lo; js < j_hi; js += a.CW) {
-    const int64_t j = js + tid;
-    const bool live = tid < a.CW && j < j_hi;
-    // ---- A'S for this column, k in chunks of 32 (accumulators in registers)
-    for (int k0 = 0; k0 < a.K; k0 += 32) {
-      float acc[32];
-#pragma unroll
-      for (int q = 0; q < 32; ++q) acc[q] = 0.f;
-      if (live) {
-        for (int l = 0; l < a.L; ++l) {
-          const float sv = a.S[(int64_t)l * a.Nv + j];
-          if (sv != 0.f) {
-            const float *ar = As + l * a.K + k0;
-#pragma unroll
-            for (int q = 0; q < 32; ++q)
-              if (k0 + q < a.K) acc[q] = fmaf(ar[q], sv, acc[q]);
-          }
-        }
-      }
-      const float al = live ? a.alpha[j] : 0.f;
-#pragma unroll
-      for (int q = 0; q < 32; ++q) {
-        const int k = k0 + q;
-        if (k < a.K) {
-          float g = 0.f;
-          if (live) {
-            const float beta = beta0 * (a.v0 + acc[q]);
-            if (final_beta) {
-              if (a.beta_dev) a.beta_dev[(j) * a.Kp + k] = beta;
-            } else {
-              const float y = a.Y[(a.c0 + j) * a.Kp + k];
-              const float b2 = beta + 0.5f * y * y;
-              lacc += (double)(-al * logf(beta) + (al + 0.5f) * logf(b2) - logf(fabsf(y) + 1e-9f));
-              g = beta0 * (-al / beta + (al + 0.5f) / b2);
-            }
-          }
-          if (!final_beta && tid < a.CW) Gt[k * GS + tid] = g;
-        }
-      }
-      if (!final_beta && live && k0 == 0) lacc -= (double)((al + 0.5f) * logf(al + 0.5f) - al * logf(al));   // calibration term, once per column
-    }
-    if (final_beta) continue;
-    __syncthreads();
-    // ---- partial grad_A[l][k] += sum_j S[l][js + j] * Gt[k][j]
-    const int ncol = (int)(j_hi - js < a.CW ? j_hi - js : a.CW);
-#pragma unroll
-    for (int o = 0; o < MAXO; ++o) {
-      const int e = tid + o * NT;
-      if (e < a.L * a.K) {
-        const int l = e / a.K, k = e - l * a.K;
-        const float *sr = a.S + (int64_t)l * a.Nv + js;
-        const float *gr = Gt + k * GS;
-        float sacc = 0.f;
-        for (int jj = 0; jj < ncol; ++jj) {
-          const float sv = sr[jj];                       // (S is sparse: most feature sets skip most columns)
-          if (sv != 0.f) sacc = fmaf(sv, gr[jj], sacc);
-        }
-        gacc[o] += sacc;
-      }
-    }
-    __syncthreads();
-  }
-  if (final_beta) return;
-#pragma unroll
-  for (int o = 0; o < MAXO; ++o) {
-    const int e = tid + o * NT;
-    if (e < a.L * a.K) a.gpart[(int64_t)blockIdx.x * a.L * a.K + e] = gacc[o];
-  }
-  const double ls = block_reduce_sum(lacc, sh);
-  if (tid == 0) a.lpart[blockIdx.x] = ls;
-}
-
-// one workgroup: loss(A_t) = sum of partials + sum lambda_k |A_lk|; bookkeeping of update_A_inner! (:239-268); then
-// ISTAOptimiser.update! (optimizers.jl:46-62) unless the loop has ended
-__global__ __launch_bounds__(1024) void k_fsard_step(const FsardArgs a) {
-  __shared__ double sh[16];
-  __shared__ int s_improved, s_done;
-  if (a.istate[0]) return;
-  const int tid = threadIdx.x, NT = blockDim.x, n = a.L * a.K;
-  double reg = 0.0;
-  for (int e = tid; e < n; e += NT) reg += (double)(a.lambda[e % a.K] * fabsf(a.A[e]));
-  // block reduce (16 waves)
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) reg += __shfl_xor(reg, off, 64);
-  if ((tid & 63) == 0) sh[tid >> 6] = reg;
-  __syncthreads();
-  if (tid == 0) {
-    double loss = 0.0;
-    for (int q = 0; q < (NT >> 6); ++q) loss += sh[q];
-    for (int w = 0; w < a.n_wg; ++w) loss += a.lpart[w];
-    const int evals = a.istate[2];
-    int improved = 0, term = a.istate[1];
-    if (evals == 0) { a.state[0] = loss; improved = 1; }                 // "Iteration 0": best_loss = loss(A), A_best = A
-    else if (loss < a.state[0]) {
-      const double diff = a.state[0] - loss;
-      a.state[0] = loss;
-      improved = 1;
-      term = diff > a.atol ? 0 : term + 1;
-    } else {
-      term += 1;
-    }
-    a.state[1] = loss;
-    a.istate[1] = term;
-    a.istate[2] = evals + 1;
-    const int done = (term >= a.istate[4]) || (evals >= a.istate[3]);    // evals == max_epochs: the last update has been evaluated
-    s_improved = improved;
-    s_done = done;
-  }
-  __syncthreads();
-  const bool improved = s_improved != 0, done = s_done != 0;
-  for (int e = tid; e < n; e += NT) {
-    float av = a.A[e];
-    if (improved) a.A_best[e] = av;
-    if (!done) {
-      float g = 0.f;
-      for (int w = 0; w < a.n_wg; ++w) g += a.gpart[(int64_t)w * n + e];   // fixed order
-      const float ssq = a.ssq[e] + g * g;                                 // optimizers.jl:50
-      a.ssq[e] = ssq;
-      const float eta = a.lr / sqrtf(ssq);                                // :51
-      av = fmaxf(av - eta * g, 0.f);                                      // :55-56
-      av = fmaxf(fabsf(av) - a.lambda[e % a.K] * eta, 0.f);               // ist_proj! :40-42, :61
-      a.A[e] = av;
-    }
-  }
-  __syncthreads();
-  if (tid == 0 && done) a.istate[0] = 1;
-}
-
-extern "C" int pmf_fsard_update_A(pmf_ctx *c, int64_t col_start1, int64_t col_stop1, int L, const float *S, const float *alpha,
-                                  const float *lambda, float alpha0, float v0, float lr, float *ssq_grad, float *A,
-                                  int max_epochs, int term_iter, double atol, double *best_loss, int *epochs_run,
-                                  float *beta_out) {
-  PMFCHK(ctx_bind(c));
-  if (c->K == 0) return pmf_fail("factors not set");
-  if (col_start1 < 1 || col_stop1 > c->N || col_start1 > col_stop1) return pmf_fail("bad column range %lld:%lld", (long long)col_start1, (long long)col_stop1);
-  if (L <= 0 || !S || !alpha || !lambda || !ssq_grad || !A) return pmf_fail("null / empty argument");
-  const int K = c->K;
-  const int64_t Nv = col_stop1 - col_start1 + 1, n = (int64_t)L * K;
-  if (n > 64 * 256) return pmf_fail("L x K = %lld exceeds the ISTA kernel's capacity (16384)", (long long)n);
-  int CW = 256;
-  while (CW > 32 && (size_t)(n + (int64_t)K * (CW + 1)) * 4 > 150 * 1024) CW >>= 1;
-  if ((size_t)(n + (int64_t)K * (CW + 1)) * 4 > 150 * 1024) return pmf_fail("L x K too large for LDS");
-  const int n_wg = (int)std::max<int64_t>(1, std::min<int64_t>(32, (Nv + CW - 1) / CW));
-  // device buffers (freed on return)
-  float *dS = nullptr, *dal = nullptr, *dlam = nullptr, *dA = nullptr, *dAb = nullptr, *dssq = nullptr, *dgp = nullptr;
-  double *dlp = nullptr, *dst = nullptr;
-  int32_t *dis = nullptr;
-  auto cleanup = [&]() { dev_free(&dS); dev_free(&dal); dev_free(&dlam); dev_free(&dA); dev_free(&dAb); dev_free(&dssq); dev_free(&dgp); dev_free(&dlp); dev_free(&dst); dev_free(&dis); };
-  int rc = 0;
-  do {
-    if ((rc = dev_alloc(&dS, (size_t)(L * Nv), false)) < 0) break;
-    if ((rc = dev_alloc(&dal, (size_t)Nv, false)) < 0) break;
-    if ((rc = dev_alloc(&dlam, (size_t)K, false)) < 0) break;
-    if ((rc = dev_alloc(&dA, (size_t)n)) < 0) break;          // A .= 0 (featureset_ard.jl:286)
-    if ((rc = dev_alloc(&dAb, (size_t)n)) < 0) break;
-    if ((rc = dev_alloc(&dssq, (size_t)n, false)) < 0) break;
-    if ((rc = dev_alloc(&dgp, (size_t)(n_wg * n))) < 0) break;
-    if ((rc = dev_alloc(&dlp, (size_t)n_wg)) < 0) break;
-    if ((rc = dev_alloc(&dst, (size_t)8)) < 0) break;
-    if ((rc = dev_alloc(&dis, (size_t)8)) < 0) break;
-    hipError_t e = hipMemcpy(dS, S, sizeof(float) * (size_t)(L * Nv), hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = hipMemcpy(dal, alpha, sizeof(float) * (size_t)Nv, hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = hipMemcpy(dlam, lambda, sizeof(float) * (size_t)K, hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = hipMemcpy(dssq, ssq_grad, sizeof(float) * (size_t)n, hipMemcpyHostToDevice);
-    const int32_t is0[8] = {0, 0, 0, max_epochs, term_iter, 0, 0, 0};
-    if (e == hipSuccess) e = hipMemcpy(dis, is0, sizeof(is0), hipMemcpyHostToDevice);
-    if (e != hipSuccess) { rc = pmf_fail("pmf_fsard_update_A: %s", hipGetErrorString(e)); break; }
-    FsardArgs a;
-    memset(&a, 0, sizeof(a));
-    a.Y = c->P[1].p; a.S = dS; a.alpha = dal; a.lambda = dlam; a.A = dA; a.A_best = dAb; a.ssq = dssq; a.gpart = dgp; a.lpart = dlp;
-    a.state = dst; a.istate = dis; a.beta_dev = (c->has_ard && c->ard_beta) ? c->ard_beta + (col_start1 - 1) * c->Kp : nullptr;
-    a.c0 = col_start1 - 1; a.Nv = Nv; a.L = L; a.K = K; a.Kp = c->Kp; a.CW = CW; a.n_wg = n_wg;
-    a.alpha0 = alpha0; a.v0 = v0; a.lr = lr; a.atol = atol;
-    const size_t lds = (size_t)(n + (int64_t)K * (CW + 1)) * 4;
-    if ((rc = ensure_dyn_lds(c, (const void *)k_fsard_grad, lds)) < 0) break;
-    int32_t h_is[8];
-    // evaluations 0 .. max_epochs (the update after evaluation t gives A_{t+1}); the host looks at the `done` flag once
-    // per batch of iterations
-    const int batch = std::max(8, term_iter);
-    bool done = false;
-    for (int t = 0; t <= max_epochs && !done; t += batch) {
-      for (int q = 0; q < batch && t + q <= max_epochs; ++q) {
-        hipLaunchKernelGGL(k_fsard_grad, dim3(n_wg), dim3(256), lds, c->stream, a, 0);
-        hipLaunchKernelGGL(k_fsard_step, dim3(1), dim3(1024), 0, c->stream, a);
-      }
-      e = hipGetLastError();
-      if (e == hipSuccess) e = hipMemcpyAsync(h_is, dis, sizeof(h_is), hipMemcpyDeviceToHost, c->stream);
-      if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-      if (e != hipSuccess) { rc = pmf_fail("pmf_fsard_update_A: %s", hipGetErrorString(e)); break; }
-      done = h_is[0] != 0;
-    }
-    if (rc < 0) break;
-    // A .= A_best ; beta[:, cr] = beta0 (v0 + A'S)   (featureset_ard.jl:272, 292)
-    float *dbeta_tmp = nullptr;
-    if (beta_out && !a.beta_dev) {   // no device regularizer array to write into: a temporary with the view's columns
-      if ((rc = dev_alloc(&dbeta_tmp, (size_t)(Nv * c->Kp))) < 0) break;
-      a.beta_dev = dbeta_tmp;
-    }
-    if (a.beta_dev) hipLaunchKernelGGL(k_fsard_grad, dim3(n_wg), dim3(256), lds, c->stream, a, 1);
-    double h_st[8];
-    e = hipMemcpyAsync(h_st, dst, sizeof(h_st), hipMemcpyDeviceToHost, c->stream);
-    if (e == hipSuccess) e = hipMemcpyAsync(h_is, dis, sizeof(h_is), hipMemcpyDeviceToHost, c->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-    if (e == hipSuccess) e = hipMemcpy(A, dAb, sizeof(float) * (size_t)n, hipMemcpyDeviceToHost);
-    if (e == hipSuccess) e = hipMemcpy(ssq_grad, dssq, sizeof(float) * (size_t)n, hipMemcpyDeviceToHost);
-    if (e == hipSuccess && beta_out)
-      e = hipMemcpy2D(beta_out, sizeof(float) * K, a.beta_dev, sizeof(float) * c->Kp, sizeof(float) * K, (size_t)Nv, hipMemcpyDeviceToHost);
-    dev_free(&dbeta_tmp);
-    if (e != hipSuccess) { rc = pmf_fail("pmf_fsard_update_A: %s", hipGetErrorString(e)); break; }
-    if (best_loss) *best_loss = h_st[0];
-    if (epochs_run) *epochs_run = h_is[2] - 1;
-  } while (0);
-  cleanup();
-  return rc;
-}
 
 static int run_forward(pmf_ctx *c, float *Zdev, int synth, uint64_t seed, float noise, float frac_nan, int64_t nRB = 0) {
   PMFCHK(check_ready(c));

@@ -229,3 +229,87 @@ def test_two_ranks_layer_stage_through_the_c_loop(ctx, tmp_path):
         assert rel_err(o["layers"], np.concatenate([np.asarray(a, np.float64).ravel() for a in ref])) <= 2e-4
     np.testing.assert_array_equal(outs[0]["layers"], outs[1]["layers"])
     np.testing.assert_array_equal(outs[0]["loss2"], outs[1]["loss2"])
+
+
+# ---- automatic column chunks must be a COLLECTIVE decision (rank-invariant inputs): two ranks with shards of different
+# heights near the threshold where the local rule of round 2 gave S = 1 on one rank and S = 2 on the other
+AUTO_N, AUTO_K = 5120, 64                 # 160 column tiles
+AUTO_ROWS = (102 * 256, 104 * 256 + 5)    # 102 and 105 row panels; mean 26370 rows = 104 panels: 104 * 160 / 2 >= 32 * 256 -> S = 2
+
+
+def _worker_auto(rank, world, port, outdir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch
+    import torch.distributed as dist
+    import pmf_import
+    pkg = pmf_import.load()
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    ctx = pkg.Context(0)
+
+    def allreduce(arr):
+        dist.all_reduce(torch.from_numpy(arr))
+
+    ctx.comm_init_host(rank, world, allreduce)          # (no comm_set_chunks: automatic)
+    Ml, N, K = AUTO_ROWS[rank], AUTO_N, AUTO_K
+    rng_y = np.random.default_rng(7)
+    Yt = (rng_y.standard_normal((K, N)) * 0.3).astype(np.float32)
+    Y0 = (rng_y.standard_normal((K, N)) * 0.1).astype(np.float32)
+    rng_x = np.random.default_rng(8 + rank)
+    Xt = (rng_x.standard_normal((K, Ml)) * 0.3).astype(np.float32)
+    X0 = (rng_x.standard_normal((K, Ml)) * 0.1).astype(np.float32)
+    ctx.set_data_device(None, Ml, N)
+    ctx.set_factors(Xt, Yt)
+    ctx.set_col_params(np.zeros(N, np.float32), np.zeros(N, np.float32))
+    ctx.set_batch_views([])
+    ctx.set_noise([(1, N)], ["normal"], np.ones(N, np.float32))
+    ctx.synth_data(seed=100 + rank, noise=0.1)
+    ctx.set_factors(X0, Y0)
+    ctx.clear_xreg()
+    ctx.clear_yreg()
+    ctx.add_yreg_fsard(np.full(N, 1.001, np.float32), np.full((K, N), 0.001, np.float32))
+    ctx.set_optimizer("adam", lr=0.01)
+    h = ctx.fit(update_X=True, update_Y=True, max_epochs=4, abs_tol=0, rel_tol=0)
+    info = ctx.comm_info()
+    _, Y = ctx.get_factors()
+    np.savez(Path(outdir) / f"auto{rank}.npz", loss=h["loss"], n_chunks=info["n_chunks"], n_coll=info["n_collectives"], Y=Y)
+    ctx.comm_destroy()
+    ctx.close()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_unequal_shards_choose_the_same_automatic_chunks(tmp_path):
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    code = ("import sys; sys.path[:0] = [%r, %r]; import test_gpu_comm as t; "
+            "t._worker_auto(int(sys.argv[1]), 2, int(sys.argv[2]), sys.argv[3])") % (str(ROOT), str(ROOT / "tests"))
+    procs = [subprocess.Popen([sys.executable, "-c", code, str(r), str(port), str(tmp_path)]) for r in range(2)]
+    for pr in procs:
+        assert pr.wait(timeout=600) == 0
+    a, b = (np.load(tmp_path / f"auto{k}.npz") for k in range(2))
+    assert int(a["n_chunks"]) == int(b["n_chunks"]) == 2, (int(a["n_chunks"]), int(b["n_chunks"]))
+    assert int(a["n_coll"]) == int(b["n_coll"])
+    np.testing.assert_array_equal(a["loss"], b["loss"])
+    np.testing.assert_array_equal(a["Y"], b["Y"])
+    assert a["loss"][-1] < a["loss"][0]
+
+
+def test_one_rank_rccl_with_the_per_communicator_cta_cap(pkg, ctx, monkeypatch):
+    """ncclCommInitRankConfig (maxCTAs = the reserved CUs) is how a multi-rank communicator is created; a one-rank
+    communicator takes the same path under PMF_COMM_CAP_ONE_RANK and must work and give the plain fit's bits."""
+    p = make_problem(**CASE)
+    r0, X0, Y0 = _fit(ctx, p, "adagrad", update_X=True, update_Y=True)
+    monkeypatch.setenv("PMF_COMM_CAP_ONE_RANK", "1")
+    assert "NCCL_MAX_NCHANNELS" not in os.environ
+    ctx.comm_init(0, 1, pkg._lib.comm_unique_id())
+    try:
+        r1, X1, Y1 = _fit(ctx, p, "adagrad", update_X=True, update_Y=True)
+        assert ctx.comm_info()["n_collectives"] >= 2 * EPOCHS
+        out = ctx.comm_allreduce(np.arange(5, dtype=np.float64))
+        np.testing.assert_array_equal(out, np.arange(5, dtype=np.float64))
+    finally:
+        ctx.comm_destroy()
+    assert "NCCL_MAX_NCHANNELS" not in os.environ      # the library sets nothing process-wide
+    np.testing.assert_array_equal(r1["loss"], r0["loss"])
+    np.testing.assert_array_equal(X1, X0)
+    np.testing.assert_array_equal(Y1, Y0)

@@ -406,3 +406,28 @@ def test_blocks_of_missing_samples_match_oracle(ctx, K):
     r = ctx.fit(update_X=True, update_Y=True, max_epochs=6, abs_tol=0, rel_tol=0)
     ro = to_oracle(p).fit(update_X=True, update_Y=True, lr=0.05, max_epochs=6, abs_tol=0, rel_tol=0)
     np.testing.assert_allclose(r["loss"], ro["loss"], rtol=5e-5)
+
+
+@pytest.mark.parametrize("precision", ["f32", "bf16x3"])
+@pytest.mark.parametrize("K", [64, 128])
+def test_multi_rank_grid_with_reserved_cus_matches_oracle(ctx, monkeypatch, precision, K):
+    """With more than one rank the data pass leaves 4 CUs to RCCL: a 252-workgroup grid, not a multiple of the 8 XCDs
+    (pmf_xcd_wg's uneven case).  PMF_RESERVE_CUS=4 runs that grid on one rank: loss and gradients against the oracle, exact
+    and split kernels."""
+    p = make_problem(seed=23, M=700, N=3000, K=K, nan_frac=0.03, weights=True, col_params=True, xreg="l2", yreg="fsard")
+    monkeypatch.setenv("PMF_RESERVE_CUS", "4")
+    ctx.set_precision(precision)
+    try:
+        to_context(p, ctx)
+        n0 = ctx.get_precision()[1]
+        loss, g = grads_of(ctx, p, update_X=True, update_Y=True)
+        took_split = ctx.get_precision()[1] > n0
+    finally:
+        ctx.set_precision("f32")
+    assert took_split == (precision == "bf16x3")
+    m = to_oracle(p)
+    m.m.n_xreg = 0
+    m.m.n_yreg = 0
+    _, gd = m.loss_and_grads(update_X=True, update_Y=True)
+    assert abs(loss - gd["data_loss"]) <= LOSS_RTOL * abs(gd["data_loss"]) + 1e-6
+    assert rel_err(g["X"], gd["X"]) <= GRAD_TOL and rel_err(g["Y"], gd["Y"]) <= GRAD_TOL, (rel_err(g["X"], gd["X"]), rel_err(g["Y"], gd["Y"]))
