@@ -160,8 +160,24 @@ def blas_epoch(D, X, Y, logsigma, mu, w, wq_x, alpha, beta, optX, optY, capacity
     return loss
 
 
+def _blas_limit():
+    """BLAS threads = the CPUs this process may use (OpenBLAS sizes its pool by the host's core count: 64 threads on a
+    16-CPU cgroup share is slower than 16)."""
+    try:
+        from threadpoolctl import threadpool_limits
+        return threadpool_limits(limits=usable_cpus(), user_api="blas")
+    except Exception:
+        import contextlib
+        return contextlib.nullcontext()
+
+
 def blas_port(N, K, rows, epochs, seed, opt, lr):
     """Seconds per epoch of the BLAS-structured port on a rows x N sample; returns (s_per_epoch, blas_threads)."""
+    with _blas_limit():
+        return _blas_port(N, K, rows, epochs, seed, opt, lr)
+
+
+def _blas_port(N, K, rows, epochs, seed, opt, lr):
     D, X, Y, edges = _problem(N, K, rows, seed)
     X = np.asfortranarray(X).copy(order="C")
     logsigma = np.zeros(N, np.float32)
@@ -191,8 +207,10 @@ def sgemm_rate(m=2048, n=4096, k=64, reps=3):
     rng = np.random.default_rng(0)
     a = rng.standard_normal((m, k), dtype=np.float32)
     b = rng.standard_normal((k, n), dtype=np.float32)
-    a @ b
-    t0 = time.perf_counter()
-    for _ in range(reps):
+    with _blas_limit():
         a @ b
-    return 2.0 * m * n * k * reps / (time.perf_counter() - t0) / 1e9
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            a @ b
+        dt = time.perf_counter() - t0
+    return 2.0 * m * n * k * reps / dt / 1e9

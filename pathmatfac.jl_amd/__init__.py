@@ -18,3 +18,5 @@ from .featureset_ard import update_A_, update_lambda_  # noqa: F401
 from .transform import transform  # noqa: F401
 from . import model_io  # noqa: F401
 from .model_io import save_params_npz, load_params_npz  # noqa: F401
+from . import data_io  # noqa: F401
+from .data_io import load_omic_data, load_batches, save_omic_npz, model_from_data_file  # noqa: F401
