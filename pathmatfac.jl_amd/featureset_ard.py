@@ -1,39 +1,9 @@
-"""FeatureSetARD outer loop: update_lambda!, update_A! with the projected-AdaGrad ISTA optimiser
-(src/featureset_ard.jl:154-294, src/optimizers.jl:26-62).
-
-These are K x N_v / L_v x K dense updates (<= 1000 iterations per view per outer iteration); they run as torch
-tensor ops on the GPU (rocBLAS GEMMs for A'S and S*grad', elementwise kernels for the rest) so Y never leaves the
-device-side precision path.  There is no CPU fallback: without a GPU torch device the call raises."""
+"""FeatureSetARD outer loop, host side: update_lambda! (src/featureset_ard.jl:189-209, a K-vector per view from
+row means of Y) and the per-view driver of update_A! (:278-294).  The ISTA iterations themselves -- gamma_normal_loss and
+its pull-back (:154-186), ISTAOptimiser.update! (src/optimizers.jl:26-62), the bookkeeping of update_A_inner! (:214-276) --
+run on the device inside libpmf_hip.so (pmf_fsard_update_A, csrc/pmf_fsard.hip: two small HIP kernels per iteration, no
+torch, no BLAS library).  There is no CPU fallback: without the library and a GPU the call raises."""
 import numpy as np
-
-
-def _device():
-    import torch
-    if not torch.cuda.is_available():
-        raise RuntimeError("update_A_ needs a GPU (torch.cuda is not available); there is no CPU fallback")
-    return torch.device("cuda")
-
-
-def gamma_normal_loss(A, S, alpha, alpha0, v0, Y):
-    """featureset_ard.jl:154-162 (torch tensors)."""
-    import torch
-    beta0 = alpha0 - 1
-    beta = beta0 * (v0 + A.T @ S)
-    a5 = alpha + 0.5
-    lss = -torch.sum(alpha[None, :] * torch.sum(torch.log(beta), dim=0, keepdim=True)) \
-        + torch.sum(a5[None, :] * torch.sum(torch.log(beta + 0.5 * (Y * Y)), dim=0, keepdim=True))
-    lss = lss - torch.sum((a5 * torch.log(a5) - alpha * torch.log(alpha))[None, :]
-                          + torch.sum(torch.log(torch.abs(Y) + 1e-9), dim=0, keepdim=True))
-    return lss
-
-
-def gamma_normal_grad_A(A, S, alpha, alpha0, v0, Y):
-    """The rrule's pull-back (featureset_ard.jl:164-178): grad_A = S * grad_AtS'."""
-    beta0 = alpha0 - 1
-    beta = beta0 * (v0 + A.T @ S)
-    a5 = alpha + 0.5
-    grad_AtS = beta0 * ((-alpha[None, :] / beta) + a5[None, :] / (beta + 0.5 * (Y * Y)))
-    return S @ grad_AtS.T
 
 
 def update_lambda_(reg, Y):
@@ -46,39 +16,6 @@ def update_lambda_(reg, Y):
         den = Y_ms - min_ms + 1e-3
         new.append(((A.shape[0] * float(np.mean(S))) / den).astype(np.float32))
     reg.lambda_ = tuple(new)
-
-
-def update_A_inner_(A, S, Yv, alpha, alpha0, v0, lr, lam, ssq_grad, max_epochs=1000, term_iter=20, atol=1e-5,
-                    verbosity=1, print_prefix="", print_iter=100):
-    """update_A_inner! (featureset_ard.jl:214-276) with ISTAOptimiser.update! (optimizers.jl:46-62). torch tensors."""
-    import torch
-
-    def total(Am):
-        return gamma_normal_loss(Am, S, alpha, alpha0, v0, Yv) + torch.sum(lam[None, :] * torch.abs(Am))
-    best = float(total(A))
-    A_best = A.clone()
-    term_count = 0
-    for epoch in range(1, max_epochs + 1):
-        g = gamma_normal_grad_A(A, S, alpha, alpha0, v0, Yv)
-        ssq_grad += g * g                                  # optimizers.jl:50
-        eta = lr / torch.sqrt(ssq_grad)                    # :51
-        A -= eta * g                                       # :55
-        A.clamp_(min=0)                                    # :56
-        A.copy_(torch.clamp(torch.abs(A) - lam[None, :] * eta, min=0))   # ist_proj! :40-42, :61
-        new = float(total(A))
-        if new < best:
-            diff = best - new
-            best = new
-            A_best.copy_(A)
-            term_count = 0 if diff > atol else term_count + 1
-        else:
-            term_count += 1
-        if verbosity > 1 and epoch % print_iter == 0:
-            print(f"{print_prefix}Iteration {epoch}:\t Loss={new}")
-        if term_count >= term_iter:
-            break
-    A.copy_(A_best)
-    return best
 
 
 def update_A_(reg, Y, max_epochs=1000, term_iter=20, atol=1e-5, verbosity=1, print_prefix="", print_iter=100, ctx=None):

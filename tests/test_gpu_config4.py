@@ -1,0 +1,154 @@
+"""BASELINE configs[4] as ONE workload (1M x 100k, K = 128, full model, D stored bf16, bf16 MFMA; one rank's shard =
+125000 x 100000): K = 128, two batch views x 8 row batches, 20 % Bernoulli columns, 10 % missing entries, column scale /
+shift, group regularizer on X + feature-set-ARD on Y, data rounded to bf16 -- all through pmf_fused_sb4_kernel (the launch
+counter is asserted):
+
+  * at oracle size: loss, both gradients (data term, and total with the regularizers kept), a 6-epoch trajectory, against the
+    fp64 oracle fed the same bf16-rounded matrix;
+  * at the per-rank shard size (125000 x 100000, --store bf16, full model): the size-independent properties of
+    test_config2_full_size_properties -- loss against the independent statistics kernel, Richardson directional derivative,
+    bitwise reproducible loss / gX / gY.
+"""
+import numpy as np
+import pytest
+
+from problems import make_problem, rel_err, to_context, to_oracle
+from test_gpu_parity import FIT_TOL, GRAD_TOL, LOSS_RTOL, grads_of
+from test_gpu_split_bf16 import bf16_round
+
+pytestmark = pytest.mark.gpu
+
+CONFIG4 = dict(K=128, bernoulli_frac=0.2, n_views=2, batch_views=2, n_batches=8, nan_frac=0.1, weights=True, col_params=True,
+               xreg="group", yreg="fsard", n_groups=6, scale=0.35)
+
+
+@pytest.fixture()
+def sctx(ctx):
+    ctx.set_precision("bf16x3")
+    n0 = ctx.get_precision()[1]
+    yield ctx, n0
+    ctx.set_precision("f32")
+
+
+@pytest.mark.parametrize("shape", [(900, 700), (2600, 420)])
+def test_config4_loss_and_gradients_match_oracle(sctx, shape):
+    ctx, n0 = sctx
+    p = make_problem(seed=51, M=shape[0], N=shape[1], **CONFIG4)
+    p["D"] = np.asfortranarray(bf16_round(p["D"]))
+    to_context(p, ctx)
+    ctx.set_data(p["D"], store="bf16")
+    try:
+        loss, g = grads_of(ctx, p, update_X=True, update_Y=True)
+        assert ctx.get_precision() == ("bf16x3", n0 + 1), "pmf_fused_sb4_kernel was not launched"
+        assert ctx.last_path()["bmode"] == 1                          # batch layers through the LDS table (panel-local slots)
+        m = to_oracle(p)
+        lo, go = m.loss_and_grads(update_X=True, update_Y=True)
+        m.m.n_xreg = 0
+        m.m.n_yreg = 0
+        _, gd = m.loss_and_grads(update_X=True, update_Y=True)
+        assert abs(loss - gd["data_loss"]) <= LOSS_RTOL * abs(gd["data_loss"]), (loss, gd["data_loss"])
+        assert rel_err(g["X"], gd["X"]) <= GRAD_TOL, rel_err(g["X"], gd["X"])
+        assert rel_err(g["Y"], gd["Y"]) <= GRAD_TOL, rel_err(g["Y"], gd["Y"])
+        # with the regularizers kept: total loss, and total gradients recovered from Adam's first moment after one step at lr -> 0
+        ctx.set_optimizer("adam", lr=1e-30, beta1=0.9)
+        o = ctx.make_opts(update_X=True, update_Y=True)
+        ctx.epoch_begin(o)
+        ctx.epoch_step_local(o)
+        ctx.epoch_step_shared(o)
+        tot, _ = ctx.epoch_loss()
+        assert abs(tot - lo) <= LOSS_RTOL * abs(lo), (tot, lo)
+        for which in ("X", "Y"):
+            _, mom = ctx.get_opt_state(which)
+            assert rel_err(mom.astype(np.float64) / 0.1, go[which]) <= GRAD_TOL, which
+    finally:
+        ctx.set_data(p["D"])
+
+
+@pytest.mark.parametrize("opt", ["adam", "adagrad"])
+def test_config4_fit_trajectory_matches_oracle(sctx, opt):
+    ctx, n0 = sctx
+    p = make_problem(seed=53, M=900, N=700, random_init=True, **CONFIG4)
+    p["D"] = np.asfortranarray(bf16_round(p["D"]))
+    lr = 0.01 if opt == "adam" else 0.05
+    to_context(p, ctx)
+    ctx.set_data(p["D"], store="bf16")
+    try:
+        ctx.set_optimizer(opt, lr=lr)
+        r = ctx.fit(update_X=True, update_Y=True, max_epochs=6, abs_tol=0, rel_tol=0)
+        assert ctx.get_precision()[1] == n0 + 6
+        X, Y = ctx.get_factors()
+    finally:
+        ctx.set_data(p["D"])
+    m = to_oracle(p)
+    ro = m.fit(update_X=True, update_Y=True, opt=opt, lr=lr, max_epochs=6, abs_tol=0, rel_tol=0)
+    assert r["term_code"] == ro["term_code"] and r["epochs"] == ro["epochs"]
+    np.testing.assert_allclose(r["loss"], ro["loss"], rtol=5e-5)
+    tol = 8 * FIT_TOL if opt == "adagrad" else 2 * FIT_TOL      # (AdaGrad's first steps are +-lr sign(g): tests/test_gpu_split_bf16.py)
+    assert rel_err(X, m.X) <= tol and rel_err(Y, m.Y) <= tol, (rel_err(X, m.X), rel_err(Y, m.Y))
+
+
+def test_config4_shard_size_properties(sctx):
+    """One rank's shard of configs[4]: 125000 x 100000, K = 128, D stored bf16 (25 GB), full model."""
+    ctx, n0 = sctx
+    M, N, K = 125000, 100000, 128
+    rng = np.random.default_rng(9)
+    nb, nbat = N // 5, 8
+    X0 = (rng.standard_normal((K, M), dtype=np.float32) * 0.2)
+    Y0 = (rng.standard_normal((K, N), dtype=np.float32) * 0.2)
+    w = (0.5 + rng.random(N)).astype(np.float32)
+    logsigma = (0.1 * rng.standard_normal(N)).astype(np.float32)
+    mu = (0.3 * rng.standard_normal(N)).astype(np.float32)
+    views = []
+    for (s, e) in ((1, N // 2), (N // 2 + 1, N)):
+        bor = np.sort(rng.integers(0, nbat, size=M)).astype(np.int32)
+        views.append(dict(start1=s, stop1=e, batch_of_row=bor,
+                          logdelta=(0.25 * rng.standard_normal((nbat, e - s + 1))).astype(np.float32),
+                          theta=(0.25 * rng.standard_normal((nbat, e - s + 1))).astype(np.float32)))
+    ctx.set_data_device(None, M, N, store="bf16")
+    try:
+        ctx.set_factors(X0, Y0)
+        ctx.set_col_params(logsigma, mu)
+        ctx.set_batch_views(views)
+        ctx.set_noise([(1, nb), (nb + 1, N)], ["bernoulli", "normal"], w)
+        ctx.clear_xreg()
+        ctx.clear_yreg()
+        ctx.set_layer_regs()
+        ctx.synth_data(seed=321, noise=0.3, frac_nan=0.1)
+        Xs = X0 + 0.05 * rng.standard_normal((K, M), dtype=np.float32)
+        Ys = Y0 + 0.05 * rng.standard_normal((K, N), dtype=np.float32)
+        o = ctx.make_opts(update_X=True, update_Y=True)
+
+        def loss_grad(X, Y, want_grad=True):
+            ctx.set_factors(X, Y)
+            ctx.epoch_begin(o)
+            loss, _ = ctx.epoch_loss()
+            return (loss, ctx.get_grad("X"), ctx.get_grad("Y")) if want_grad else loss
+
+        L0, gX, gY = loss_grad(Xs, Ys)
+        assert ctx.get_precision() == ("bf16x3", n0 + 1) and ctx.last_path()["bmode"] == 1
+        L0b, gXb, gYb = loss_grad(Xs, Ys)
+        assert L0 == L0b and np.array_equal(gY, gYb) and np.array_equal(gX, gXb)
+        del gXb, gYb
+        st = ctx.stats(use_factors=True)
+        n_obs = float(st["n"].astype(np.float64).sum())
+        assert abs(n_obs / (float(M) * N) - 0.9) < 1e-3
+        L_gauss = 0.5 * float(np.sum(w[nb:].astype(np.float64) * st["sqerr"][nb:].astype(np.float64)))
+        n_bern = float(st["n"][:nb].astype(np.float64).sum())
+        assert 0.05 < (L0 - L_gauss) / n_bern < 1.5, (L0, L_gauss, n_bern)
+        g2 = float(np.sum(gX.astype(np.float64) ** 2) + np.sum(gY.astype(np.float64) ** 2))
+        e = 0.01 * L0 / g2
+        r = []
+        for ee in (e, 0.5 * e):
+            Le = loss_grad(Xs - np.float32(ee) * gX, Ys - np.float32(ee) * gY, want_grad=False)
+            r.append((L0 - Le) / (ee * g2))
+        assert 0.5 < r[0] < 1.0 and r[0] < r[1] < 1.0, r
+        assert abs(2 * r[1] - r[0] - 1.0) <= 1e-2, r
+        # the Gaussian columns alone against pmf_stats exactly
+        w0 = w.copy()
+        w0[:nb] = 0.0
+        ctx.set_noise([(1, nb), (nb + 1, N)], ["bernoulli", "normal"], w0)
+        Lg = loss_grad(Xs, Ys, want_grad=False)
+        assert abs(Lg - L_gauss) <= 5e-5 * L_gauss, (Lg, L_gauss)
+    finally:
+        ctx.set_data_device(None, 64, 64)      # release the 25 GB matrix
+        ctx.set_batch_views([])
