@@ -5,7 +5,6 @@
 #endif
 #include "pmf_common.h"
 #include "pmf_fused_sb2.hip.inc"
-#include "pmf_fused_sb2p.hip.inc"
 
 #if PMF_DB
 #define PMF_SB2NAME pmf_launch_fused_sb2_bf16
@@ -20,14 +19,7 @@ int PMF_SB2NAME(PmfDynLds *cache, hipStream_t stream, const FusedArgs &a, int gr
                                          : pmf_fused_sb2_kernel<MX, false, true, BT, PMF_DB != 0>)
   kern = batch ? PMF_SB_PICK_G(true, true) : (mixed ? PMF_SB_PICK_G(true, false) : PMF_SB_PICK_G(false, false));
 #undef PMF_SB_PICK_G
-  size_t lds = Sb2Cfg::lds_bytes + (batch ? Sb2Cfg::lds_batch(a.n_bv) : 0);
-  // the headline case (both gradients, Gaussian columns, no batch layers) has a software-pipelined variant
-  // (pmf_fused_sb2p.hip.inc), parity-green but 3-6 % SLOWER than the plain kernel: opt-in, PMF_SB2P=1
-  const char *pe = getenv("PMF_SB2P");
-  if (!batch && !mixed && want_gx && want_gy && pe && atoi(pe) == 1) {
-    kern = pmf_fused_sb2p_kernel<PMF_DB != 0>;
-    lds = Sb2pCfg::lds_bytes;
-  }
+  const size_t lds = Sb2Cfg::lds_bytes + (batch ? Sb2Cfg::lds_batch(a.n_bv) : 0);
   PMFCHK(pmf_ensure_dyn_lds(cache, (const void *)kern, lds));
   hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, stream, a);
   HIPCHK(hipGetLastError());

@@ -27,7 +27,7 @@ assert ctx.lib.pmf_debug_stamps(buf.ctypes.data_as(C.POINTER(C.c_ulonglong)), bu
 st = buf.reshape(-1, 16).astype(np.float64)
 st = st[st.sum(1) > 0]
 import os
-if os.environ.get("PMF_SB2P", "1") != "0":
+if os.environ.get("PMF_SB2P", "0") == "1":   # (only with scripts/experiments/sb2_row_block_pipeline.patch applied)
     names_p = {0: "tile top", 1: "phase 1: forward A | slab reduce", 2: "phase 2: forward B | epilogue A", 3: "phase 3: GEMM2+3 A | epilogue B",
                4: "phase 4: GEMM2+3 B | loads", 10: "B2 wait", 9: "slab writes (LDS)", 5: "stage_store", 6: "B1 wait", 11: "piece prologue / flush"}
 else:

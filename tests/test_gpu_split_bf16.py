@@ -332,24 +332,3 @@ def test_bf16_stored_data_through_the_exact_kernel(ctx, name):
                 assert rel_err(gl["logdelta"][v], go["logdelta"][v]) <= GRAD_TOL
     finally:
         ctx.set_data(p["D"])
-
-
-def test_pipelined_sb2_variant_matches_oracle(sctx, monkeypatch):
-    """PMF_SB2P=1: the software-pipelined variant of the K <= 64 split kernel (csrc/pmf_fused_sb2p.hip.inc; inline-asm MFMAs
-    with explicit register files, epilogue of one row block behind the MFMAs of the other).  Opt-in because it is slower
-    (DESIGN.md 4.6), kept parity-green: both of its loops (all-finite pieces without the mask, others with it)."""
-    ctx, n0 = sctx
-    monkeypatch.setenv("PMF_SB2P", "1")
-    for k, name in enumerate(["ragged_k64_nan", "many_panels_two_tiles", "one_row_panel_many_cols", "mixed_k48"]):
-        p = make_problem(seed=31 + k, **dict(CASES[name], bernoulli_frac=0.0, poisson_frac=0.0))
-        to_context(p, ctx)
-        loss, g = grads_of(ctx, p, update_X=True, update_Y=True)
-        m = to_oracle(p)
-        m.m.n_xreg = 0
-        m.m.n_yreg = 0
-        _, gd = m.loss_and_grads(update_X=True, update_Y=True)
-        assert abs(loss - gd["data_loss"]) <= LOSS_RTOL * abs(gd["data_loss"]) + 1e-6, (name, loss, gd["data_loss"])
-        assert rel_err(g["X"], gd["X"]) <= GRAD_TOL, (name, rel_err(g["X"], gd["X"]))
-        assert rel_err(g["Y"], gd["Y"]) <= GRAD_TOL, (name, rel_err(g["Y"], gd["Y"]))
-    assert ctx.get_precision()[1] == n0 + 4
-
