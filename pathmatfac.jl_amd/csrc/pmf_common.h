@@ -330,7 +330,8 @@ struct LayerPassArgs {
   const float4 *colp;
   const int32_t *bor;      // n_bv x M row -> batch (or -1)
   const float2 *btd;       // dense batch table [N padded to 32][nbs] {delta, theta}; null when there are no batch views
-  float2 *LG;              // [N][nbs] {S_G, S_Q}, zeroed by the host before the launch
+  float2 *LG;              // [R * NW * 2][N][nbs] {S_G, S_Q}: one PRIVATE table per (row range rr, wave, lane half), zeroed by the host
+  int64_t lg_stride;       // before the launch (float2 per table = N << nbs_shift); k_layer_map sums the tables in fixed order
   int32_t nbs_shift;       // nbs = 1 << nbs_shift slots per column (last = identity: row in no batch); 16 without batch views
   double *loss_partial;    // one per workgroup; null = the loss is computed elsewhere (combined epochs)
   int64_t M, N;
@@ -338,7 +339,9 @@ struct LayerPassArgs {
 };
 
 struct LayerMapArgs {
-  const float2 *LG;
+  const float2 *LG;        // n_parts private tables of lg_stride float2 each (see LayerPassArgs)
+  int64_t lg_stride;
+  int32_t n_parts;
   const float2 *btd;
   const float4 *colp;
   float *g_logsigma, *g_mu, *g_logdelta, *g_theta;   // any may be null

@@ -103,8 +103,10 @@ struct pmf_ctx {
   float2 *btab = nullptr;
   bool views_dirty = true;        // `views` changed since the last upload
   ViewDesc *d_views = nullptr;    // device copy of `views` for the fused kernel's global-gather fallback
-  float2 *LG = nullptr;           // [N][16] {S_G, S_Q} of the layer pass (pmf_layers.hip.inc)
+  float2 *LG = nullptr;           // [R * waves * 2][N][nbs] {S_G, S_Q}: the private tables of the layer pass (pmf_layers.hip.inc)
   int64_t LG_cap = 0;
+  float *lgrad_part = nullptr;    // [block rows][2N + 2 nbt] private partials of k_layer_grad (fixed-order k_sum_parts)
+  size_t lgrad_part_cap = 0;
   float2 *btd = nullptr;          // dense per-column batch table [ceil(N/32)*32][nbs] (fused kernels, layer pass); see k_dense_btab
   int64_t btd_cap = 0;
   bool btd_ok = false;            // the dense table is built (every view has <= 255 batches)

@@ -289,7 +289,11 @@ struct LayerGradArgs {
   const float4 *colp;
   const int32_t *bor;
   const float2 *btab;
-  float *g_logsigma, *g_mu, *g_logdelta, *g_theta;  // any may be null
+  float *g_logsigma, *g_mu, *g_logdelta, *g_theta;  // any may be null (only nullness is used by the kernel: see part)
+  // per block row (blockIdx.y) one private vector [mu N][logsigma N][theta nbt][logdelta nbt] of part_stride floats, every entry
+  // written by exactly one thread; k_sum_parts adds the block rows in fixed order (no float atomics: bitwise reproducible)
+  float *part;
+  int64_t part_stride, nbt;
   double *loss_partial;                             // may be null; one slot per block (flattened grid)
   int64_t M, N, nRB;
   int Kp, K, rows_per_block, max_nb;
@@ -297,10 +301,25 @@ struct LayerGradArgs {
   int64_t val_off[PMF_MAXV];
 };
 
+// out[e] = sum over p = 0 .. n_parts-1, in that order, of part[p * stride + e]
+__global__ __launch_bounds__(256) void k_sum_parts(const float *__restrict__ part, int64_t stride, int n_parts, float *__restrict__ out, int64_t n) {
+  const int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (e >= n) return;
+  float t = 0.f;
+  for (int p = 0; p < n_parts; ++p) t += part[(int64_t)p * stride + e];
+  out[e] = t;
+}
+static int sum_parts(pmf_ctx *c, const float *part, int64_t stride, int n_parts, float *out, int64_t n) {
+  if (!out || n <= 0) return 0;
+  k_sum_parts<<<(unsigned)((n + 255) / 256), 256, 0, c->stream>>>(part, stride, n_parts, out, n);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
 // One wave per workgroup: thread = column (64 consecutive columns), sequential over a chunk of rows.  The column of Y
 // lives in registers (32*KB floats), four rows of X at a time are staged in LDS and read back as broadcast 16-B reads
 // (a single wave needs no barrier: LDS operations of one wave complete in order), per-(batch, column) sums in LDS
-// (no contention), one atomic per (batch, column) per workgroup at the end.
+// (no contention), one plain store per (batch, column) per workgroup at the end (private partials, see LayerGradArgs).
 template <int KB>
 __global__ __launch_bounds__(64) void k_layer_grad(const LayerGradArgs a) {
   constexpr int Kp = 32 * KB;
@@ -396,15 +415,16 @@ __global__ __launch_bounds__(64) void k_layer_grad(const LayerGradArgs a) {
     }
   }
   if (col_ok) {
-    if (a.g_mu) atomicAdd(a.g_mu + j, smu);
-    if (a.g_logsigma) atomicAdd(a.g_logsigma + j, sls * cp.x);
+    float *pp = a.part + (int64_t)blockIdx.y * a.part_stride;
+    if (a.g_mu) pp[j] = smu;
+    if (a.g_logsigma) pp[a.N + j] = sls * cp.x;
     if (v >= 0) {
       for (int b = 0; b < vd.nb; ++b) {
         const int64_t e = a.val_off[v] + (j - vd.c0) * vd.nb + b;
-        if (a.g_theta) atomicAdd(a.g_theta + e, bacc[b * 64 + tid]);
+        if (a.g_theta) pp[2 * a.N + e] = bacc[b * 64 + tid];
         if (a.g_logdelta) {
           const float dlt = a.btab[vd.tab_off + (j - vd.c0) * vd.nb + b].x;
-          atomicAdd(a.g_logdelta + e, bacc[(a.max_nb + b) * 64 + tid] * dlt);
+          pp[2 * a.N + a.nbt + e] = bacc[(a.max_nb + b) * 64 + tid] * dlt;
         }
       }
     }
@@ -422,8 +442,9 @@ struct StatsArgs {
   const float4 *colp;
   const int32_t *bor;
   const float2 *btab;
-  float *col_n, *col_sum, *col_sumsq, *col_sqerr, *col_ssqg;  // N each
-  float *b_n, *b_sqerr;                                       // flat like theta (may be null)
+  float *col_n, *col_sum, *col_sumsq, *col_sqerr, *col_ssqg;  // N each: block row 0's vector of the PRIVATE partials -- block row y
+  float *b_n, *b_sqerr;                                       // writes at + y * part_stride; flat like theta (may be null)
+  int64_t part_stride;                                        // k_sum_parts adds the block rows in fixed order (no float atomics)
   int64_t M, N, nRB;
   int Kp, K, rows_per_block, max_nb, use_factors;
   ViewDesc views[PMF_MAXV];
@@ -513,16 +534,17 @@ __global__ __launch_bounds__(64) void k_stats(const StatsArgs a) {
     }
   }
   if (col_ok) {
-    if (a.col_n) atomicAdd(a.col_n + j, sn);
-    if (a.col_sum) atomicAdd(a.col_sum + j, s1);
-    if (a.col_sumsq) atomicAdd(a.col_sumsq + j, s2);
-    if (a.col_sqerr) atomicAdd(a.col_sqerr + j, se);
-    if (a.col_ssqg) atomicAdd(a.col_ssqg + j, sg);
+    const int64_t po = (int64_t)blockIdx.y * a.part_stride;
+    if (a.col_n) a.col_n[po + j] = sn;
+    if (a.col_sum) a.col_sum[po + j] = s1;
+    if (a.col_sumsq) a.col_sumsq[po + j] = s2;
+    if (a.col_sqerr) a.col_sqerr[po + j] = se;
+    if (a.col_ssqg) a.col_ssqg[po + j] = sg;
     if (v >= 0 && a.b_n) {
       for (int b = 0; b < vd.nb; ++b) {
         const int64_t e = a.val_off[v] + (j - vd.c0) * vd.nb + b;
-        atomicAdd(a.b_n + e, bacc[b * 64 + tid]);
-        atomicAdd(a.b_sqerr + e, bacc[(a.max_nb + b) * 64 + tid]);
+        a.b_n[po + e] = bacc[b * 64 + tid];
+        a.b_sqerr[po + e] = bacc[(a.max_nb + b) * 64 + tid];
       }
     }
   }
@@ -684,7 +706,7 @@ extern "C" int pmf_destroy(pmf_ctx *c) {
   if (c->D) (void)hipFree(c->D);
   c->D = nullptr;
   dev_free(&c->tflags);
-  dev_free(&c->bor); dev_free(&c->btab); dev_free(&c->btd); c->btd_cap = 0; c->btd_ok = false; dev_free(&c->colview); c->colview_cap = 0; dev_free(&c->LG); c->LG_cap = 0; dev_free(&c->d_views); c->views_dirty = true; dev_free(&c->d_val_view);
+  dev_free(&c->bor); dev_free(&c->btab); dev_free(&c->btd); c->btd_cap = 0; c->btd_ok = false; dev_free(&c->colview); c->colview_cap = 0; dev_free(&c->LG); c->LG_cap = 0; dev_free(&c->lgrad_part); c->lgrad_part_cap = 0; dev_free(&c->d_views); c->views_dirty = true; dev_free(&c->d_val_view);
   dev_free(&c->colmeta); dev_free(&c->colw); dev_free(&c->colp);
   dev_free(&c->ard_alpha); dev_free(&c->ard_beta);
   comm_release(c);
@@ -752,7 +774,7 @@ static int data_shape_changed(pmf_ctx *c, int64_t M, int64_t N) {
   c->views_dirty = true;
   c->val_off.clear();
   c->bvb_off.clear();
-  dev_free(&c->bor); dev_free(&c->btab); dev_free(&c->btd); c->btd_cap = 0; c->btd_ok = false; dev_free(&c->colview); c->colview_cap = 0; dev_free(&c->LG); c->LG_cap = 0; dev_free(&c->d_views); c->views_dirty = true; dev_free(&c->d_val_view);
+  dev_free(&c->bor); dev_free(&c->btab); dev_free(&c->btd); c->btd_cap = 0; c->btd_ok = false; dev_free(&c->colview); c->colview_cap = 0; dev_free(&c->LG); c->LG_cap = 0; dev_free(&c->lgrad_part); c->lgrad_part_cap = 0; dev_free(&c->d_views); c->views_dirty = true; dev_free(&c->d_val_view);
   PMFCHK(dev_alloc(&c->colmeta, (size_t)N));
   PMFCHK(dev_alloc(&c->colw, (size_t)N));
   PMFCHK(dev_alloc(&c->colp, (size_t)N));
@@ -1833,6 +1855,15 @@ static int launch_layer_grad(pmf_ctx *c, const pmf_fit_opts *o, bool with_loss) 
     c->n_macro = nslots;
     a.loss_partial = c->loss_partial;
   }
+  // private partials per block row, summed in fixed order afterwards (every entry of a vector is written by its block)
+  const int64_t nbt = c->n_bv > 0 ? c->val_off[c->n_bv] : 0;
+  a.nbt = nbt;
+  a.part_stride = 2 * c->N + 2 * nbt;
+  if ((size_t)(a.part_stride * gy) > c->lgrad_part_cap) {
+    PMFCHK(dev_alloc(&c->lgrad_part, (size_t)(a.part_stride * gy), false));
+    c->lgrad_part_cap = (size_t)(a.part_stride * gy);
+  }
+  a.part = c->lgrad_part;
   const size_t lds = sizeof(float) * (size_t)(4 * c->Kp + 2 * max_nb * 64);
   if (lds > 160 * 1024) return pmf_fail("too many row batches per view (%d) for the layer-gradient kernel", max_nb);
   void (*kern)(const LayerGradArgs) = nullptr;
@@ -1846,6 +1877,10 @@ static int launch_layer_grad(pmf_ctx *c, const pmf_fit_opts *o, bool with_loss) 
   PMFCHK(ensure_dyn_lds(c, (const void *)kern, lds));
   hipLaunchKernelGGL(kern, dim3(gx, (unsigned)gy), dim3(64), lds, c->stream, a);
   HIPCHK(hipGetLastError());
+  PMFCHK(sum_parts(c, a.part, a.part_stride, (int)gy, a.g_mu, c->N));
+  PMFCHK(sum_parts(c, a.part + c->N, a.part_stride, (int)gy, a.g_logsigma, c->N));
+  PMFCHK(sum_parts(c, a.part + 2 * c->N, a.part_stride, (int)gy, a.g_theta, nbt));
+  PMFCHK(sum_parts(c, a.part + 2 * c->N + nbt, a.part_stride, (int)gy, a.g_logdelta, nbt));
   return 0;
 }
 
@@ -1871,11 +1906,14 @@ static int launch_layer_pass(pmf_ctx *c, const pmf_fit_opts *o, bool with_loss) 
   const int64_t n_seg = (n_ct + PMF_LS - 1) / PMF_LS;
   int64_t R = std::max<int64_t>(1, std::min<int64_t>(n_rp, (4ll * c->n_cu + n_seg - 1) / n_seg));
   const int grid = (int)std::min<int64_t>(n_seg * R, c->n_cu);
-  if (c->N * nbs > c->LG_cap) {
-    PMFCHK(dev_alloc(&c->LG, (size_t)(c->N * nbs), false));
-    c->LG_cap = c->N * nbs;
+  // one private [N][nbs] table per (row range, wave, lane half): plain read-modify-writes instead of float atomics, summed
+  // in fixed order by k_layer_map.  R * N is bounded by ~4 n_cu * 64 columns, so the tables take ~130 MB at nbs = 16.
+  const int64_t lg_stride = c->N * nbs, n_parts = R * lnw * 2;
+  if (lg_stride * n_parts > c->LG_cap) {
+    PMFCHK(dev_alloc(&c->LG, (size_t)(lg_stride * n_parts), false));
+    c->LG_cap = lg_stride * n_parts;
   }
-  HIPCHK(hipMemsetAsync(c->LG, 0, sizeof(float2) * (size_t)(c->N * nbs), c->stream));
+  HIPCHK(hipMemsetAsync(c->LG, 0, sizeof(float2) * (size_t)(lg_stride * n_parts), c->stream));
   if (with_loss) {
     if (grid > c->loss_cap) {
       PMFCHK(dev_alloc(&c->loss_partial, (size_t)grid));
@@ -1886,14 +1924,14 @@ static int launch_layer_pass(pmf_ctx *c, const pmf_fit_opts *o, bool with_loss) 
   LayerPassArgs a;
   memset(&a, 0, sizeof(a));
   a.D = c->D; a.d_bf16 = c->store == PMF_STORE_BF16; a.nRB = c->nRB; a.X = c->P[0].p; a.Y = c->P[1].p; a.colp = c->colp; a.bor = c->bor;
-  a.btd = c->n_bv > 0 ? c->btd : nullptr; a.LG = c->LG; a.loss_partial = with_loss ? c->loss_partial : nullptr;
+  a.btd = c->n_bv > 0 ? c->btd : nullptr; a.LG = c->LG; a.lg_stride = lg_stride; a.loss_partial = with_loss ? c->loss_partial : nullptr;
   a.M = c->M; a.N = c->N; a.n_bv = c->n_bv; a.n_ct = (int)n_ct; a.n_rp = (int)n_rp; a.n_seg = (int)n_seg; a.R = (int)R;
   a.nbs_shift = nbs_shift;
   PMFCHK(pmf_launch_layer_pass(&c->dyn_lds, c->stream, c->KB, lnw, c->mixed, grid, a));
   LayerMapArgs m;
   memset(&m, 0, sizeof(m));
   const int fl = o->frozen_layers;
-  m.LG = c->LG; m.btd = a.btd; m.colp = c->colp; m.N = c->N; m.n_bv = c->n_bv; m.nbs_shift = nbs_shift;
+  m.LG = c->LG; m.lg_stride = lg_stride; m.n_parts = (int32_t)n_parts; m.btd = a.btd; m.colp = c->colp; m.N = c->N; m.n_bv = c->n_bv; m.nbs_shift = nbs_shift;
   m.g_logsigma = (fl & 1) ? nullptr : c->P[2].g;
   m.g_logdelta = ((fl & 2) || c->n_bv == 0) ? nullptr : c->P[4].g;
   m.g_mu = (fl & 4) ? nullptr : c->P[3].g;
@@ -2120,15 +2158,9 @@ extern "C" int pmf_stats(pmf_ctx *c, int use_factors, float *col_n, float *col_s
   PMFCHK(prepare(c));
   const int64_t nbt = c->n_bv > 0 ? c->val_off[c->n_bv] : 0;
   const size_t nfl = (size_t)(5 * c->N + 2 * nbt);
-  PMFCHK(ensure_scratch(c, sizeof(float) * std::max<size_t>(nfl, 1)));
-  float *buf = (float *)c->scratch;
-  HIPCHK(hipMemsetAsync(buf, 0, sizeof(float) * nfl, c->stream));
   StatsArgs a;
   memset(&a, 0, sizeof(a));
   a.D = c->D; a.d_bf16 = c->store == PMF_STORE_BF16; a.X = c->P[0].p; a.Y = c->P[1].p; a.colp = c->colp; a.bor = c->bor; a.btab = c->btab;
-  a.col_n = buf; a.col_sum = buf + c->N; a.col_sumsq = buf + 2 * c->N; a.col_sqerr = buf + 3 * c->N; a.col_ssqg = buf + 4 * c->N;
-  a.b_n = nbt ? buf + 5 * c->N : nullptr;
-  a.b_sqerr = nbt ? buf + 5 * c->N + nbt : nullptr;
   a.M = c->M; a.N = c->N; a.nRB = c->nRB; a.Kp = c->Kp; a.K = c->K; a.use_factors = use_factors;
   int max_nb = 1;
   for (int v = 0; v < c->n_bv; ++v) {
@@ -2141,6 +2173,14 @@ extern "C" int pmf_stats(pmf_ctx *c, int use_factors, float *col_n, float *col_s
   int64_t gy = std::max<int64_t>(1, std::min<int64_t>((32ll * c->n_cu + gx - 1) / gx, (c->M + 255) / 256));
   a.rows_per_block = (int)((c->M + gy - 1) / gy);
   gy = (c->M + a.rows_per_block - 1) / a.rows_per_block;
+  // scratch: [results nfl][gy private partial vectors of nfl]; every entry of a partial vector is written by its block row,
+  // the block rows are then added in fixed order (k_sum_parts): no float atomics, bitwise reproducible statistics
+  PMFCHK(ensure_scratch(c, sizeof(float) * std::max<size_t>(nfl * (size_t)(gy + 1), 1)));
+  float *buf = (float *)c->scratch, *part = buf + nfl;
+  a.part_stride = (int64_t)nfl;
+  a.col_n = part; a.col_sum = part + c->N; a.col_sumsq = part + 2 * c->N; a.col_sqerr = part + 3 * c->N; a.col_ssqg = part + 4 * c->N;
+  a.b_n = nbt ? part + 5 * c->N : nullptr;
+  a.b_sqerr = nbt ? part + 5 * c->N + nbt : nullptr;
   const size_t lds = sizeof(float) * (size_t)(4 * c->Kp + 2 * max_nb * 64);
   if (lds > 160 * 1024) return pmf_fail("too many row batches per view (%d) for the statistics kernel", max_nb);
   void (*kst)(const StatsArgs) = nullptr;
@@ -2154,12 +2194,13 @@ extern "C" int pmf_stats(pmf_ctx *c, int use_factors, float *col_n, float *col_s
   PMFCHK(ensure_dyn_lds(c, (const void *)kst, lds));
   hipLaunchKernelGGL(kst, dim3(gx, (unsigned)gy), dim3(64), lds, c->stream, a);
   HIPCHK(hipGetLastError());
+  PMFCHK(sum_parts(c, part, (int64_t)nfl, (int)gy, buf, (int64_t)nfl));
   HIPCHK(hipStreamSynchronize(c->stream));
   float *outs[5] = {col_n, col_sum, col_sumsq, col_sqerr, col_ssq_grad};
   for (int q = 0; q < 5; ++q)
     if (outs[q]) HIPCHK(hipMemcpy(outs[q], buf + (int64_t)q * c->N, sizeof(float) * (size_t)c->N, hipMemcpyDeviceToHost));
-  if (batch_count && nbt) HIPCHK(hipMemcpy(batch_count, a.b_n, sizeof(float) * (size_t)nbt, hipMemcpyDeviceToHost));
-  if (batch_sqerr && nbt) HIPCHK(hipMemcpy(batch_sqerr, a.b_sqerr, sizeof(float) * (size_t)nbt, hipMemcpyDeviceToHost));
+  if (batch_count && nbt) HIPCHK(hipMemcpy(batch_count, buf + 5 * c->N, sizeof(float) * (size_t)nbt, hipMemcpyDeviceToHost));
+  if (batch_sqerr && nbt) HIPCHK(hipMemcpy(batch_sqerr, buf + 5 * c->N + nbt, sizeof(float) * (size_t)nbt, hipMemcpyDeviceToHost));
   return 0;
 }
 

@@ -33,6 +33,10 @@ int pmf_launch_layer_pass(PmfDynLds *cache, hipStream_t stream, int KB, int lnw,
 }
 
 int pmf_launch_layer_map(hipStream_t stream, const LayerMapArgs &m) {
+  if (m.n_parts > 1) {
+    k_layer_reduce<<<(unsigned)((m.lg_stride + 255) / 256), 256, 0, stream>>>(const_cast<float2 *>(m.LG), m.lg_stride, m.n_parts);
+    HIPCHK(hipGetLastError());
+  }
   k_layer_map<<<(unsigned)((m.N + 255) / 256), 256, 0, stream>>>(m);
   HIPCHK(hipGetLastError());
   return 0;

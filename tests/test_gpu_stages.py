@@ -201,3 +201,43 @@ def test_theta_delta_em_matches_independent_oracle(pkg):
         for g, w in zip(got_d2, want_d2):
             assert rel_err(g, w) <= 2e-4, rel_err(g, w)
         model.release_device()
+
+
+# ---- bitwise reproducibility of the layer pass and of pmf_stats (no float atomics: private partials + fixed-order sums) ----
+@pytest.mark.parametrize("path", ["mfma", "valu"])
+@pytest.mark.parametrize("shape", [dict(M=3000, N=700, K=32, n_batches=8), dict(M=1500, N=300, K=100, n_batches=24)])
+def test_layer_gradients_and_stats_are_bitwise_reproducible(ctx, monkeypatch, path, shape):
+    """grad(theta), grad(logdelta), grad(mu), grad(logsigma) and every output of pmf_stats must be the same BITS run to run, on
+    the MFMA layer pass (narrow and wide batch tables) and on the scalar fall-back kernel; theta after a 10-epoch lr = 1 theta
+    stage (discrete loss_increase decisions, src/fit.jl:63, 106-122) likewise."""
+    from problems import make_problem, to_context
+    if path == "valu":
+        monkeypatch.setenv("PMF_LAYER_OLD", "1")
+    p = make_problem(seed=71, bernoulli_frac=0.2, n_views=2, batch_views=2, nan_frac=0.1, weights=True, col_params=True,
+                     layer_regs=True, random_init=True, scale=0.5, batch_order="mixed", **shape)
+    runs = []
+    for _ in range(2):
+        to_context(p, ctx)
+        ctx.set_optimizer("adagrad", lr=1.0)
+        o = ctx.make_opts(update_col_layers=True)
+        ctx.epoch_begin(o)
+        loss = ctx.epoch_loss()[0]
+        assert ctx.last_path()["layer_path"] == (1 if path == "mfma" else 2)
+        g = [ctx.get_grad("mu"), ctx.get_grad("logsigma")] + [ctx.get_grad(w, v) for w in ("theta", "logdelta") for v in range(2)]
+        st = ctx.stats(use_factors=True)
+        r = ctx.fit(update_col_layers=True, frozen_layers=0b0111, max_epochs=10, abs_tol=0, rel_tol=0)
+        th = [ctx.get_batch_view(v)[1] for v in range(2)]
+        runs.append((loss, g, st, r["loss"], th))
+    a, b = runs
+    assert a[0] == b[0]
+    for x, y in zip(a[1], b[1]):
+        np.testing.assert_array_equal(x, y)
+    for k in a[2]:
+        if isinstance(a[2][k], (list, tuple)):
+            for x, y in zip(a[2][k], b[2][k]):
+                np.testing.assert_array_equal(x, y)
+        else:
+            np.testing.assert_array_equal(a[2][k], b[2][k])
+    np.testing.assert_array_equal(a[3], b[3])
+    for x, y in zip(a[4], b[4]):
+        np.testing.assert_array_equal(x, y)
