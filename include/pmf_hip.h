@@ -245,6 +245,9 @@ int pmf_comm_info(pmf_ctx *ctx, int *rank, int *nranks, int *transport, int *n_c
  * more than 15 batches stay on variant 1 as long as no 256-row (128-row for K > 64) panel holds more than 15 distinct
  * batches of one view (src/batch_array.jl:78-147 places no bound on the batch count). */
 int pmf_debug_last_path(pmf_ctx *ctx, int *bmode, int *layer_path, int *slots);
+/* the kernel family the last fused data pass ran on: 0 exact f32 (pmf_fused_kernel), 1 pmf_fused_sb_kernel, 2 pmf_fused_sb2_kernel,
+ * 4 pmf_fused_sb4_kernel, 8 pmf_fused_sb8_kernel (split modes; tests assert that the intended variant really ran) */
+int pmf_debug_last_kernel(pmf_ctx *ctx, int *kernel);
 
 /* raw device addresses of the gradient buffers (float32) and their element counts, for in-place collectives */
 int pmf_grad_device_ptr(pmf_ctx *ctx, int which, void **ptr, int64_t *n_elements);

@@ -50,7 +50,7 @@ EXPORTS = [
     "pmf_grad_device_ptr", "pmf_get_grad", "pmf_forward", "pmf_stats", "pmf_kernel_time", "pmf_synth_data",
     "pmf_set_precision", "pmf_get_precision",
     "pmf_comm_get_unique_id", "pmf_comm_init", "pmf_comm_init_host", "pmf_comm_destroy", "pmf_comm_set_chunks",
-    "pmf_comm_info", "pmf_comm_allreduce", "pmf_get_opt_state", "pmf_fsard_update_A", "pmf_debug_last_path",
+    "pmf_comm_info", "pmf_comm_allreduce", "pmf_get_opt_state", "pmf_fsard_update_A", "pmf_debug_last_path", "pmf_debug_last_kernel",
 ]
 
 COMM_ID_BYTES = 128
@@ -467,6 +467,12 @@ class Context:
         b, l, s = C.c_int(0), C.c_int(0), C.c_int(0)
         self._chk(self.lib.pmf_debug_last_path(self._h, C.byref(b), C.byref(l), C.byref(s)))
         return dict(bmode=b.value, layer_path=l.value, slots=s.value)
+
+    def last_kernel(self):
+        """Kernel family of the last fused data pass: 0 exact, 1 / 2 / 4 / 8 the split kernels sb / sb2 / sb4 / sb8."""
+        k = C.c_int(0)
+        self._chk(self.lib.pmf_debug_last_kernel(self._h, C.byref(k)))
+        return k.value
 
     def set_precision(self, mode):
         """'f32' (exact f32 MFMA, default) or 'bf16x3' (split-bf16 products where a kernel variant exists)."""

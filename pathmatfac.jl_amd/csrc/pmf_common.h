@@ -101,6 +101,9 @@ struct FusedArgs {
   float *gx_part;
   const int32_t *piece_base;   // [grid]
   int64_t gx_slot_stride;      // floats per slot = BM * Kp
+  // pmf_fused_sb8_kernel: power-of-two pre-scales of the f16 operand images of X and of sigma*Y (device scalars written by
+  // k_sb8_scale right before the images; the forward accumulators are multiplied by 1 / (sx sy))
+  const float *sb_scale_x, *sb_scale_y;
 };
 
 __device__ __forceinline__ int pmf_rowmap(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
@@ -249,6 +252,42 @@ struct Sb4SplitArgs {
   int32_t Ksrc, transposed;   // transposed: also write the two transposed images (X); block stride 5 images, else 3
   char *out;
 };
+// ---- pmf_fused_sb8_kernel (pmf_fused_sb8.hip.inc): K = 128 (96 < K <= 128), 256-row panel, four waves x two row blocks.
+// The forward product runs on f16 PAIRS (hi = f16(s a), lo' = f16((s a - hi) 2^11); s a power of two that brings max|a| to
+// [2^12, 2^13)): 22 significant bits in two terms and three MFMAs per k-step (hi hi into one accumulator, hi lo' + lo' hi into a
+// second one worth 2^-11) -- 1e-7 of max|Z| at every operand scale (scripts/f16x2_probe.hip), where bf16 needs three terms
+// and six MFMAs.  The gradient products stay on bf16 (hi, mid), whose range needs no care.
+// Operand block of 32 rows: [f16 hi][f16 lo'] row images (256-byte rows, pmf_sb4_off swizzle) + two bf16 images:
+//   X: hi, mid TRANSPOSED ([k][i], 64-byte rows, 16-B chunk c of row k at c ^ ((k >> 2) & 3): conflict-free ds_read_b128 with
+//      lane = k) -- GEMM3's B operand;   Y: hi, mid row images (pmf_sb4_off) -- GEMM2's B operand through transposed reads.
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+__host__ __device__ __forceinline__ int pmf_sb8_xt_off(int k, int c) { return 64 * k + 16 * (c ^ ((k >> 2) & 3)); }
+struct Sb8Cfg {
+  static constexpr int NW = 4, RB = 2, Kp = 128, BM = 32 * NW * RB;
+  static constexpr int IMG = 32 * 256;
+  static constexpr int XBLK = 4 * IMG, YBLK = 4 * IMG;
+  // LDS: Y bf16 hi + mid (double buffered) | Y f16 hi + lo' (single) | eight G images (hi, lo: 4 KiB each) | X^T hi of the
+  // panel's eight row blocks | column parameters, tile kind, loss partials
+  static constexpr size_t lds_bytes = (2 * 2 * IMG + 2 * IMG + 8 * 4096 + 8 * IMG + 8 * PMF_BN * 4 + 16 + 8 * NW + 15) / 16 * 16;
+  static constexpr size_t lds_batch(int n_bv) { return PMF_BN * 16 * sizeof(float2) + PMF_PM_BYTES + (size_t)NW * RB * n_bv * 32; }
+  static constexpr int max_bv = PMF_MAXV;
+};
+struct Sb8SplitArgs {
+  const float *src;       // [n][Kp] f32
+  const float4 *colp;     // .x = sigma (Y) or null (X)
+  const float *scale;     // device scalar: power-of-two pre-scale of the f16 images
+  int64_t n, nblk;
+  int32_t transposed;     // X: the bf16 images are the transposed ones
+  char *out;
+};
+struct Sb8ScaleArgs {
+  const float *src;
+  const float4 *colp;
+  int64_t n;              // rows of src (Kp = 128 floats each)
+  uint32_t *max_bits;     // scratch word (zeroed by the launcher)
+  float *scale_out;       // the device scalar the images and the fused kernel read
+};
+
 // Index into the dense batch table of entry (column j, panel-local slot s) for a column of view vw (255 = none), given the
 // piece's slot -> batch map Pm (LDS, [n_bv][16]).  Unused slots and columns outside every view hit the identity slot.
 // (32-bit element index: the host keeps the table below 2^31 entries, so the load is scalar base + one offset register)
@@ -373,6 +412,10 @@ int pmf_launch_fused_sb4_4_bf16(PmfDynLds *cache, hipStream_t stream, const Fuse
 int pmf_launch_fused_sb4_3(PmfDynLds *cache, hipStream_t stream, const FusedArgs &a, int grid, bool batch, bool mixed, bool want_gx, bool want_gy);
 int pmf_launch_fused_sb4_3_bf16(PmfDynLds *cache, hipStream_t stream, const FusedArgs &a, int grid, bool batch, bool mixed, bool want_gx, bool want_gy);
 int pmf_launch_sb4_split(hipStream_t stream, const Sb4SplitArgs &a);
+int pmf_launch_fused_sb8(PmfDynLds *cache, hipStream_t stream, const FusedArgs &a, int grid, bool batch, bool mixed);
+int pmf_launch_fused_sb8_bf16(PmfDynLds *cache, hipStream_t stream, const FusedArgs &a, int grid, bool batch, bool mixed);
+int pmf_launch_sb8_split(hipStream_t stream, const Sb8SplitArgs &a);
+int pmf_launch_sb8_scale(hipStream_t stream, const Sb8ScaleArgs &a);
 int pmf_launch_sb_split_1(hipStream_t stream, const SbSplitArgs &a);
 int pmf_launch_sb_split_2(hipStream_t stream, const SbSplitArgs &a);
 size_t pmf_layer_pass_lds(int KB, int lnw, int nbs);   // dynamic LDS of the layer pass (<= 160 KiB: eligible)

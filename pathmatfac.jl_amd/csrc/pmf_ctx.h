@@ -116,6 +116,7 @@ struct pmf_ctx {
   std::vector<std::vector<int32_t>> h_bor;   // host copy of batch_of_row per view (panel-local slot maps)
   PanelSlots pslots[3];           // panel-local batch slots for row panels of 128 / 256 / 512 rows (ensure_panel_slots)
   int64_t views_serial = 0;       // bumped whenever a view's rows / shape change
+  int last_kernel = 0;            // fused kernel family of the last data pass (pmf_debug_last_kernel)
   int last_bmode = 0, last_layer_path = 0;   // diagnostics (pmf_debug_last_path)
   int32_t *d_val_view = nullptr;  // per flat value element: view id
   // noise model / prepared column parameters
@@ -151,6 +152,8 @@ struct pmf_ctx {
   int precision = PMF_PREC_F32;   // products of the fused data pass: exact f32 MFMA, or split-bf16 (pmf_set_precision)
   char *xsb = nullptr, *ysb = nullptr;   // split-bf16 operand images of X / sigma*Y, rebuilt every epoch (k_sb_split)
   size_t xsb_cap = 0, ysb_cap = 0;       // bytes
+  float *sb8_scale = nullptr;     // [1 + chunks] power-of-two pre-scales of pmf_fused_sb8_kernel's f16 images: X, then Y per chunk
+  uint32_t *sb8_max = nullptr;    // [1 + chunks] bit patterns of max |operand| (k_sb8_absmax)
   int64_t sb_launches = 0;        // fused launches that took the split-bf16 kernel (pmf_get_precision)
   int64_t loss_cap = 0;
   int64_t n_macro = 0;
@@ -180,6 +183,7 @@ struct FusedGeom {
   int bmode = 0;      // batch layers: 0 none, 1 LDS table with panel-local slots, 2 per-entry global gathers (fallback)
   PanelSlots *ps = nullptr;
   bool sb = false;    // split-bf16 products: pmf_fused_sb_kernel (K <= 64) or pmf_fused_sb4_kernel (64 < K <= 128)
+  bool sb8 = false;   // ... of them, pmf_fused_sb8_kernel: 96 < K <= 128, both gradients, 256-row panel
   int64_t n_rp = 0, n_ct_all = 0;
   int64_t ct0[PMF_MAX_CHUNKS], nct[PMF_MAX_CHUNKS];
 };

@@ -714,7 +714,7 @@ extern "C" int pmf_destroy(pmf_ctx *c) {
   for (auto &ws : c->splits) { dev_free(&ws.wg_begin); dev_free(&ws.c_off); dev_free(&ws.c_idx); dev_free(&ws.piece_base); dev_free(&ws.d_piece_base_abs); }
   dev_free(&c->gx_part); dev_free(&c->gx_off); dev_free(&c->gx_idx);
   if (c->ev_host) (void)hipEventDestroy(c->ev_host);
-  dev_free(&c->gy_slabs); dev_free(&c->xsb); dev_free(&c->ysb); dev_free(&c->loss_partial); dev_free(&c->reg_partial); dev_free(&c->d_loss);
+  dev_free(&c->gy_slabs); dev_free(&c->xsb); dev_free(&c->ysb); dev_free(&c->sb8_scale); dev_free(&c->sb8_max); dev_free(&c->loss_partial); dev_free(&c->reg_partial); dev_free(&c->d_loss);
   if (c->h_loss) (void)hipHostFree(c->h_loss);
   if (c->scratch) (void)hipFree(c->scratch);
   for (auto &e : c->ev_pool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
@@ -1304,7 +1304,8 @@ static int ensure_tile_flags(pmf_ctx *c) {
 // sequence) it touched tile ti iff its range, taken relative to the segment start, contains an index == ti mod tps_cs.
 __global__ __launch_bounds__(64) void k_gy_reduce(const float *__restrict__ slabs, int64_t stride,
                                                   const int32_t *__restrict__ c_off, const int32_t *__restrict__ c_idx,
-                                                  int Kp, int64_t N, float *__restrict__ gY, int ct0) {
+                                                  int Kp, int64_t N, float *__restrict__ gY, int ct0,
+                                                  const float4 *__restrict__ colscale) {   // non-null: the slabs hold sums NOT yet scaled by sigma_j (pmf_fused_sb8_kernel)
   // blockIdx.x = column tile of the chunk that starts at tile ct0, blockIdx.y = 256-float slice of its 32 x Kp elements (one float4 per thread).  The
   // workgroups that visited the tile are listed in c_idx[c_off[ct] .. c_off[ct+1]) (built on the host with the work
   // split, compute_work_split); their slabs are summed four at a time so that four independent loads are in flight.
@@ -1333,9 +1334,10 @@ __global__ __launch_bounds__(64) void k_gy_reduce(const float *__restrict__ slab
     const float4 v = *reinterpret_cast<const float4 *>(base + (int64_t)ci[c] * stride);
     a0.x += v.x; a0.y += v.y; a0.z += v.z; a0.w += v.w;
   }
+  const float sg = colscale ? colscale[(e0 + q) / Kp].x : 1.f;   // (the four elements belong to one column: Kp is a multiple of 4)
   *reinterpret_cast<float4 *>(gY + e0 + q) =
-      make_float4((a0.x + a1.x) + (a2.x + a3.x), (a0.y + a1.y) + (a2.y + a3.y), (a0.z + a1.z) + (a2.z + a3.z),
-                  (a0.w + a1.w) + (a2.w + a3.w));
+      make_float4(((a0.x + a1.x) + (a2.x + a3.x)) * sg, ((a0.y + a1.y) + (a2.y + a3.y)) * sg, ((a0.z + a1.z) + (a2.z + a3.z)) * sg,
+                  ((a0.w + a1.w) + (a2.w + a3.w)) * sg);
 }
 
 // gX = sum of the per-piece partial slabs of a row panel, in work-sequence order (fixed summation order: grad(X) is
@@ -1556,6 +1558,15 @@ FusedGeom fused_geometry(pmf_ctx *c, bool want_gx, bool want_gy, bool allow_chun
   const bool sb_batch_ok = c->n_bv == 0 || (g.bmode == 1 && c->n_bv <= sb_max_bv);
   g.sb = c->precision == PMF_PREC_BF16X3 && sb_batch_ok && (want_gx || want_gy) && !getenv("PMF_DEBUG_FLAGS");
   if (g.sb) g.RBW = 1;
+  // 96 < K <= 128, both gradients: the 256-row-panel kernel (pmf_fused_sb8.hip.inc: four waves x two row blocks; PMF_SB8=0
+  // keeps pmf_fused_sb4_kernel's 128-row panel).  Batch layers need the panel-local slots of the taller panel.
+  g.sb8 = g.sb && c->KB == 4 && want_gx && want_gy && !(getenv("PMF_SB8") && atoi(getenv("PMF_SB8")) == 0);
+  if (g.sb8 && c->n_bv > 0) {
+    PanelSlots *ps8 = nullptr;
+    if (ensure_panel_slots(c, Sb8Cfg::BM, &ps8) == 0 && ps8 && ps8->ok) g.ps = ps8;
+    else g.sb8 = false;
+  }
+  if (g.sb8) g.RBW = Sb8Cfg::RB;
   g.BM = 32 * g.NW * g.RBW;
   g.n_rp = (c->M + g.BM - 1) / g.BM;
   g.n_ct_all = (c->N + PMF_BN - 1) / PMF_BN;
@@ -1679,17 +1690,29 @@ int prepare_fused_pass(pmf_ctx *c, const FusedGeom &g, bool want_gx, bool want_g
   PMFCHK(ensure_tile_flags(c));
   if (g.sb) {
     const size_t xblk = c->KB == 1 ? SbCfg<1>::BLK : (c->KB == 2 ? SbCfg<2>::BLK : Sb4Cfg<4>::XBLK);
-    const size_t yblk = c->KB == 1 ? SbCfg<1>::BLK : (c->KB == 2 ? SbCfg<2>::BLK : Sb4Cfg<4>::YBLK);
+    const size_t yblk = c->KB == 1 ? SbCfg<1>::BLK : (c->KB == 2 ? SbCfg<2>::BLK : std::max<size_t>(Sb4Cfg<4>::YBLK, Sb8Cfg::YBLK));
     const size_t xb = (size_t)c->nRB * xblk, yb = (size_t)g.n_ct_all * yblk;
     if (xb > c->xsb_cap) { dev_free(&c->xsb); c->xsb_cap = 0; PMFCHK(dev_alloc(&c->xsb, xb, false)); c->xsb_cap = xb; }
     if (yb > c->ysb_cap) { dev_free(&c->ysb); c->ysb_cap = 0; PMFCHK(dev_alloc(&c->ysb, yb, false)); c->ysb_cap = yb; }
+    if (g.sb8 && !c->sb8_scale) {
+      PMFCHK(dev_alloc(&c->sb8_scale, (size_t)(1 + PMF_MAX_CHUNKS), false));
+      PMFCHK(dev_alloc(&c->sb8_max, (size_t)(1 + PMF_MAX_CHUNKS)));
+    }
   }
   return 0;
 }
 
 // split-bf16 operand images (k_sb_split): X once per pass, sigma*Y per chunk (its columns only: the Y step of a later
 // chunk of the previous epoch may not have run yet when an earlier chunk is launched, pmf_fit)
-static int sb_split_x(pmf_ctx *c) {
+// pmf_fused_sb8_kernel's images: the power-of-two pre-scale of the f16 pair first (a device scalar: no host round trip)
+static int sb8_split(pmf_ctx *c, const float *src, const float4 *colp, int64_t n, int64_t nblk, int slot, int transposed, char *out) {
+  Sb8ScaleArgs sa = {src, colp, n, c->sb8_max + slot, c->sb8_scale + slot};
+  PMFCHK(pmf_launch_sb8_scale(c->stream, sa));
+  Sb8SplitArgs sp = {src, colp, c->sb8_scale + slot, n, nblk, transposed, out};
+  return pmf_launch_sb8_split(c->stream, sp);
+}
+static int sb_split_x(pmf_ctx *c, bool sb8) {
+  if (sb8) return sb8_split(c, c->P[0].p, nullptr, c->M, c->nRB, 0, 1, c->xsb);
   if (c->KB > 2) {
     Sb4SplitArgs s4 = {c->P[0].p, nullptr, c->M, c->nRB, c->Kp, 1, c->xsb};
     return pmf_launch_sb4_split(c->stream, s4);
@@ -1697,7 +1720,12 @@ static int sb_split_x(pmf_ctx *c) {
   SbSplitArgs sx = {c->P[0].p, nullptr, c->M, c->nRB, c->xsb};
   return c->KB == 1 ? pmf_launch_sb_split_1(c->stream, sx) : pmf_launch_sb_split_2(c->stream, sx);
 }
-static int sb_split_y(pmf_ctx *c, int64_t ct0, int64_t nct) {
+static int sb_split_y(pmf_ctx *c, int64_t ct0, int64_t nct, bool sb8, int chunk) {
+  if (sb8) {
+    const int64_t c0 = ct0 * 32;
+    return sb8_split(c, c->P[1].p + c0 * c->Kp, c->colp + c0, std::min<int64_t>(c->N - c0, nct * 32), nct, 1 + chunk, 0,
+                     c->ysb + (size_t)ct0 * Sb8Cfg::YBLK);
+  }
   if (c->KB > 2) {
     const int64_t c0 = ct0 * 32;
     Sb4SplitArgs s4 = {c->P[1].p + c0 * c->Kp, c->colp + c0, c->N - c0, nct, c->Kp, 0, c->ysb + (size_t)ct0 * Sb4Cfg<4>::YBLK};
@@ -1754,9 +1782,10 @@ int launch_fused_chunk(pmf_ctx *c, const FusedGeom &g, int s, bool want_gx, bool
   a.views = c->d_views;
   const bool batch = c->n_bv > 0;
   if (g.sb) {
-    if (s == 0) PMFCHK(sb_split_x(c));
-    PMFCHK(sb_split_y(c, g.ct0[s], n_ct));
+    if (s == 0) PMFCHK(sb_split_x(c, g.sb8));
+    PMFCHK(sb_split_y(c, g.ct0[s], n_ct, g.sb8, s));
     a.Xsb = c->xsb; a.Ysb = c->ysb;
+    if (g.sb8) { a.sb_scale_x = c->sb8_scale; a.sb_scale_y = c->sb8_scale + 1 + s; }
   }
   // timing events
   if (c->ev_used == c->ev_pool.size()) {
@@ -1783,7 +1812,9 @@ int launch_fused_chunk(pmf_ctx *c, const FusedGeom &g, int s, bool want_gx, bool
                                            : (d16 ? pmf_launch_fused_sb_2_bf16 : pmf_launch_fused_sb_2))
                    : c->KB == 3 ? (d16 ? pmf_launch_fused_sb4_3_bf16 : pmf_launch_fused_sb4_3)
                                 : (d16 ? pmf_launch_fused_sb4_4_bf16 : pmf_launch_fused_sb4_4);
-    rc = fn(&c->dyn_lds, c->stream, a, grid, batch, c->mixed, want_gx, want_gy);
+    c->last_kernel = g.sb8 ? 8 : (c->KB >= 3 ? 4 : (c->KB == 2 && use_sb2 ? 2 : 1));
+    if (g.sb8) rc = (d16 ? pmf_launch_fused_sb8_bf16 : pmf_launch_fused_sb8)(&c->dyn_lds, c->stream, a, grid, batch, c->mixed);
+    else rc = fn(&c->dyn_lds, c->stream, a, grid, batch, c->mixed, want_gx, want_gy);
     c->sb_launches += 1;
   } else {
     typedef int (*ex_fn)(PmfDynLds *, hipStream_t, const FusedArgs &, int, bool, bool);
@@ -1797,13 +1828,15 @@ int launch_fused_chunk(pmf_ctx *c, const FusedGeom &g, int s, bool want_gx, bool
       case 41: fn = d16 ? pmf_launch_fused_exact_41_bf16 : pmf_launch_fused_exact_41; break;
       default: return pmf_fail("unsupported KB=%d", c->KB);
     }
+    c->last_kernel = 0;
     rc = fn(&c->dyn_lds, c->stream, a, grid, batch, c->mixed);
   }
   PMFCHK(rc);
   HIPCHK(hipEventRecord(ev.second, c->stream));   // the events bracket pmf_fused_kernel alone (= rocprofv3's kernel duration)
   if (want_gy && !(a.dbg & 8)) {
     k_gy_reduce<<<dim3((unsigned)n_ct, (unsigned)(32 * c->Kp / 256)), 64, 0, c->stream>>>(c->gy_slabs, slab_stride, ws.c_off, ws.c_idx,
-                                                                                      c->Kp, c->N, c->P[1].g, (int)g.ct0[s]);
+                                                                                      c->Kp, c->N, c->P[1].g, (int)g.ct0[s],
+                                                                                      g.sb8 ? c->colp : nullptr);
     HIPCHK(hipGetLastError());
   }
   if (want_gx && s == g.S - 1) {
@@ -2013,6 +2046,12 @@ int epoch_layer_pass(pmf_ctx *c, const pmf_fit_opts *o, bool with_loss) {
 // Which batch-layer variants the last launches took (tests and benchmarks: a silent fall-back to the slow paths is a
 // performance bug).  bmode: 0 none, 1 LDS table with panel-local slots, 2 per-entry gathers; layer_path: 1 MFMA layer
 // pass, 2 VALU layer kernel; slots: columns of the dense batch table.
+extern "C" int pmf_debug_last_kernel(pmf_ctx *c, int *kernel) {
+  if (!c) return pmf_fail("null context");
+  if (kernel) *kernel = c->last_kernel;
+  return 0;
+}
+
 extern "C" int pmf_debug_last_path(pmf_ctx *c, int *bmode, int *layer_path, int *slots) {
   if (!c) return pmf_fail("null context");
   if (bmode) *bmode = c->last_bmode;

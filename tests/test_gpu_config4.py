@@ -39,7 +39,7 @@ def test_config4_loss_and_gradients_match_oracle(sctx, shape):
     ctx.set_data(p["D"], store="bf16")
     try:
         loss, g = grads_of(ctx, p, update_X=True, update_Y=True)
-        assert ctx.get_precision() == ("bf16x3", n0 + 1), "pmf_fused_sb4_kernel was not launched"
+        assert ctx.get_precision() == ("bf16x3", n0 + 1) and ctx.last_kernel() == 8, "pmf_fused_sb8_kernel was not launched"
         assert ctx.last_path()["bmode"] == 1                          # batch layers through the LDS table (panel-local slots)
         m = to_oracle(p)
         lo, go = m.loss_and_grads(update_X=True, update_Y=True)
@@ -75,7 +75,7 @@ def test_config4_fit_trajectory_matches_oracle(sctx, opt):
     try:
         ctx.set_optimizer(opt, lr=lr)
         r = ctx.fit(update_X=True, update_Y=True, max_epochs=6, abs_tol=0, rel_tol=0)
-        assert ctx.get_precision()[1] == n0 + 6
+        assert ctx.get_precision()[1] == n0 + 6 and ctx.last_kernel() == 8
         X, Y = ctx.get_factors()
     finally:
         ctx.set_data(p["D"])
@@ -125,7 +125,7 @@ def test_config4_shard_size_properties(sctx):
             return (loss, ctx.get_grad("X"), ctx.get_grad("Y")) if want_grad else loss
 
         L0, gX, gY = loss_grad(Xs, Ys)
-        assert ctx.get_precision() == ("bf16x3", n0 + 1) and ctx.last_path()["bmode"] == 1
+        assert ctx.get_precision() == ("bf16x3", n0 + 1) and ctx.last_path()["bmode"] == 1 and ctx.last_kernel() == 8
         L0b, gXb, gYb = loss_grad(Xs, Ys)
         assert L0 == L0b and np.array_equal(gY, gYb) and np.array_equal(gX, gXb)
         del gXb, gYb
