@@ -1692,7 +1692,8 @@ int prepare_fused_pass(pmf_ctx *c, const FusedGeom &g, bool want_gx, bool want_g
     const size_t xblk = c->KB == 1 ? SbCfg<1>::BLK : (c->KB == 2 ? SbCfg<2>::BLK : Sb4Cfg<4>::XBLK);
     const size_t yblk = c->KB == 1 ? SbCfg<1>::BLK : (c->KB == 2 ? SbCfg<2>::BLK : std::max<size_t>(Sb4Cfg<4>::YBLK, Sb8Cfg::YBLK));
     const size_t xb = (size_t)c->nRB * xblk, yb = (size_t)g.n_ct_all * yblk;
-    if (xb > c->xsb_cap) { dev_free(&c->xsb); c->xsb_cap = 0; PMFCHK(dev_alloc(&c->xsb, xb, false)); c->xsb_cap = xb; }
+    // (+ eight zeroed row blocks: pmf_fused_sb8_kernel reads the blocks of a ragged last panel without clamping)
+    if (xb > c->xsb_cap) { dev_free(&c->xsb); c->xsb_cap = 0; PMFCHK(dev_alloc(&c->xsb, xb + 8 * xblk, true)); c->xsb_cap = xb; }
     if (yb > c->ysb_cap) { dev_free(&c->ysb); c->ysb_cap = 0; PMFCHK(dev_alloc(&c->ysb, yb, false)); c->ysb_cap = yb; }
     if (g.sb8 && !c->sb8_scale) {
       PMFCHK(dev_alloc(&c->sb8_scale, (size_t)(1 + PMF_MAX_CHUNKS), false));
