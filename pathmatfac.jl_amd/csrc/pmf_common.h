@@ -257,10 +257,13 @@ struct Sb4SplitArgs {
 // [2^12, 2^13)): 22 significant bits in two terms and three MFMAs per k-step (hi hi into one accumulator, hi lo' + lo' hi into a
 // second one worth 2^-11) -- 1e-7 of max|Z| at every operand scale (scripts/f16x2_probe.hip), where bf16 needs three terms
 // and six MFMAs.  The gradient products stay on bf16 (hi, mid), whose range needs no care.
-// Operand block of 32 rows: [f16 hi][f16 lo'] row images (256-byte rows, pmf_sb4_off swizzle) + two bf16 images:
+// Operand block of 32 rows: [f16 hi][f16 lo'] images in k-step-major order (pmf_sb8_f_off: the 16-B chunk of k-step S, lane
+// half h', row r at 1024 S + 512 h' + 16 r -- the 64 lanes of a forward fragment read read 1 KiB contiguous, no swizzle, and
+// the k-step is an immediate offset: one address register instead of eight) + two bf16 images:
 //   X: hi, mid TRANSPOSED ([k][i], 64-byte rows, 16-B chunk c of row k at c ^ ((k >> 2) & 3): conflict-free ds_read_b128 with
 //      lane = k) -- GEMM3's B operand;   Y: hi, mid row images (pmf_sb4_off) -- GEMM2's B operand through transposed reads.
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+__host__ __device__ __forceinline__ int pmf_sb8_f_off(int row, int ch) { return 1024 * (ch & 7) + 512 * (ch >> 3) + 16 * row; }
 __host__ __device__ __forceinline__ int pmf_sb8_xt_off(int k, int c) { return 64 * k + 16 * (c ^ ((k >> 2) & 3)); }
 struct Sb8Cfg {
   static constexpr int NW = 4, RB = 2, Kp = 128, BM = 32 * NW * RB;
