@@ -1652,7 +1652,9 @@ int prepare_fused_pass(pmf_ctx *c, const FusedGeom &g, bool want_gx, bool want_g
   const int64_t slab_stride = (int64_t)c->Kp * c->N;
   if (want_gy && (size_t)g.grid_max * (size_t)slab_stride > c->gy_slabs_cap) {
     dev_free(&c->gy_slabs);
-    PMFCHK(dev_alloc(&c->gy_slabs, (size_t)g.grid_max * (size_t)slab_stride, false));   // never read before written
+    // never read before written, EXCEPT by pmf_fused_sb8_kernel, which loads the old values of a ragged last tile's absent
+    // columns without clamping (they are accumulated and never stored): one tile of padding keeps those loads in bounds
+    PMFCHK(dev_alloc(&c->gy_slabs, (size_t)g.grid_max * (size_t)slab_stride + (size_t)PMF_BN * (size_t)c->Kp, false));
     c->gy_slabs_cap = (size_t)g.grid_max * (size_t)slab_stride;
   }
   if (want_gx && serial_sum != c->gx_serial) {

@@ -152,3 +152,56 @@ def test_config4_shard_size_properties(sctx):
     finally:
         ctx.set_data_device(None, 64, 64)      # release the 25 GB matrix
         ctx.set_batch_views([])
+
+
+# ---- pmf_fused_sb8_kernel specifics (csrc/pmf_fused_sb8.hip.inc) --------------------------------------------------------
+@pytest.mark.parametrize("sx,sy", [(1e-4, 1e4), (3e3, 1.0 / 3e3), (1e-6, 1e-3)])
+def test_sb8_f16_prescale_handles_operand_ranges(sctx, sx, sy):
+    """The forward runs on f16 pairs: operands beyond f16's range (|sigma Y| up to 1e5 here: > 65504) or far below its normal
+    range must come out like the exact product, through the power-of-two pre-scale of the operand images (k_sb8_absmax).
+    The same problem with X scaled by sx and Y by sy (first case: X'Y unchanged) against the fp64 oracle."""
+    ctx, n0 = sctx
+    p = make_problem(seed=57, M=700, N=420, K=128, nan_frac=0.05, weights=True, col_params=True, scale=0.35)
+    p["X"] = np.asfortranarray((p["X"] * sx).astype(np.float32))
+    p["Y"] = np.asfortranarray((p["Y"] * sy).astype(np.float32))
+    if abs(sx * sy - 1.0) > 1e-6:       # keep the residuals O(noise): the data follows the scaled product
+        p["D"] = np.asfortranarray(np.where(np.isnan(p["D"]), np.nan, p["D"] * np.float32(sx * sy)).astype(np.float32))
+        p["mu"] = (p["mu"] * np.float32(sx * sy)).astype(np.float32)
+    to_context(p, ctx)
+    loss, g = grads_of(ctx, p, update_X=True, update_Y=True)
+    assert ctx.last_kernel() == 8
+    m = to_oracle(p)
+    m.m.n_xreg = 0
+    m.m.n_yreg = 0
+    _, gd = m.loss_and_grads(update_X=True, update_Y=True)
+    assert np.isfinite(loss) and abs(loss - gd["data_loss"]) <= LOSS_RTOL * abs(gd["data_loss"]), (loss, gd["data_loss"])
+    assert rel_err(g["X"], gd["X"]) <= GRAD_TOL and rel_err(g["Y"], gd["Y"]) <= GRAD_TOL, (rel_err(g["X"], gd["X"]), rel_err(g["Y"], gd["Y"]))
+
+
+def test_sb8_column_chunks_and_kernel_selection(sctx):
+    """Column chunks (one launch and one pre-scale of sigma Y per chunk) give the unchunked gradients; single-gradient passes
+    and PMF_SB8=0 stay on the 128-row kernel."""
+    ctx, n0 = sctx
+    p = make_problem(seed=59, M=900, N=1300, K=128, nan_frac=0.05, weights=True, col_params=True, scale=0.35, xreg="l2", yreg="fsard")
+    to_context(p, ctx)
+    l0, g0 = grads_of(ctx, p, update_X=True, update_Y=True)
+    assert ctx.last_kernel() == 8
+    ctx.comm_set_chunks(3)
+    try:
+        l1, g1 = grads_of(ctx, p, update_X=True, update_Y=True)
+        assert ctx.last_kernel() == 8
+    finally:
+        ctx.comm_set_chunks(0)
+    assert abs(l1 - l0) <= 1e-7 * abs(l0)
+    assert rel_err(g1["X"], g0["X"]) <= 2e-6 and rel_err(g1["Y"], g0["Y"]) <= 2e-6
+    _, gx_only = grads_of(ctx, p, update_X=True)
+    assert ctx.last_kernel() == 4
+    assert rel_err(gx_only["X"], g0["X"]) <= 2e-5      # (three bf16 terms against two f16 terms in the forward: both 1e-7 of max|Z|)
+    import os
+    os.environ["PMF_SB8"] = "0"
+    try:
+        l4, g4 = grads_of(ctx, p, update_X=True, update_Y=True)
+        assert ctx.last_kernel() == 4
+    finally:
+        del os.environ["PMF_SB8"]
+    assert abs(l4 - l0) <= 2e-6 * abs(l0) and rel_err(g4["X"], g0["X"]) <= 2e-5 and rel_err(g4["Y"], g0["Y"]) <= 2e-5
