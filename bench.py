@@ -192,6 +192,8 @@ def main():
             ep = r["epochs"] + 1
         return ls
 
+    kern_names = {}   # arithmetic mode -> the kernel family the library actually ran (pmf_debug_last_kernel)
+
     def timed_run(precision):
         """W untimed + K timed epochs from the same initial factors and a fresh optimizer state."""
         ctx.set_precision(precision)
@@ -210,6 +212,8 @@ def main():
         if use_dist:
             t = float(ctx.comm_allreduce(np.array([t], np.float64), op="max")[0])
         ms, n = ctx.kernel_time()
+        kern_names[precision] = {0: "pmf_fused_kernel", 1: "pmf_fused_sb_kernel", 2: "pmf_fused_sb2_kernel", 4: "pmf_fused_sb4_kernel",
+                                 8: "pmf_fused_sb8_kernel"}.get(ctx.last_kernel(), "?")
         return t, ms, n, ls, ctx.get_precision()[1] - n_split0
 
     dt, k_ms, k_n, losses, n_split = timed_run(args.precision)
@@ -255,7 +259,7 @@ def main():
                          "hbm_peak_GBps": 8000.0},
             "loss_first": losses[0], "loss_last": losses[-1],
         }
-        sb_name = "pmf_fused_sb_kernel" if K <= 32 else ("pmf_fused_sb2_kernel" if K <= 64 else "pmf_fused_sb4_kernel")
+        sb_name = kern_names.get("bf16x3", "pmf_fused_sb_kernel" if K <= 32 else ("pmf_fused_sb2_kernel" if K <= 64 else "pmf_fused_sb8_kernel"))
         if split_main:
             # the split-bf16 kernel needs a quarter of the matrix cycles: what bounds it is the D stream
             d_gbps = dsz * Ml * N / n_chunks / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
