@@ -263,20 +263,30 @@ struct Sb4SplitArgs {
 //   X: hi, mid TRANSPOSED ([k][i], 64-byte rows, 16-B chunk c of row k at c ^ ((k >> 2) & 3): conflict-free ds_read_b128 with
 //      lane = k) -- GEMM3's B operand;   Y: hi, mid row images (pmf_sb4_off) -- GEMM2's B operand through transposed reads.
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-__host__ __device__ __forceinline__ int pmf_sb8_f_off(int row, int ch) { return 1024 * (ch & 7) + 512 * (ch >> 3) + 16 * row; }
+template <int KB>
+__host__ __device__ __forceinline__ int pmf_sb8_f_off(int row, int ch) { return 1024 * (ch % (2 * KB)) + 512 * (ch / (2 * KB)) + 16 * row; }
 __host__ __device__ __forceinline__ int pmf_sb8_xt_off(int k, int c) { return 64 * k + 16 * (c ^ ((k >> 2) & 3)); }
+// KB = 4 (96 < K <= 128): two row blocks per wave, 256-row panel.  KB = 2 (32 < K <= 64): four row blocks per wave, 512-row panel.
+// Every image of a 32-row block is 64 Kp bytes (f16 pair, bf16 pair, 64-byte-row transposed images alike).
+template <int KB>
 struct Sb8Cfg {
-  static constexpr int NW = 4, RB = 2, Kp = 128, BM = 32 * NW * RB;
-  static constexpr int IMG = 32 * 256;
+  static_assert(KB == 4 || KB == 2, "pmf_fused_sb8_kernel: KB = 4 or 2");
+  static constexpr int NW = 4, RB = 8 / KB, Kp = 32 * KB, BM = 32 * NW * RB, NBLK = NW * RB;
+  static constexpr int IMG = 64 * Kp;
   static constexpr int XBLK = 4 * IMG, YBLK = 4 * IMG;
-  // LDS: Y bf16 hi + mid (double buffered) | Y f16 hi + lo' (single) | eight G images (hi, lo: 4 KiB each) | X^T hi of the
-  // panel's eight row blocks | column parameters, tile kind, loss partials
-  static constexpr size_t lds_bytes = (2 * 2 * IMG + 2 * IMG + 8 * 4096 + 8 * IMG + 8 * PMF_BN * 4 + 16 + 8 * NW + 15) / 16 * 16;
+  // LDS: Y bf16 hi + mid (double buffered) | Y f16 hi + lo' (single) | one G image (hi, lo: 4 KiB) per row block of the panel |
+  // X^T hi of the panel's row blocks | column parameters, tile kind / view, loss partials
+  static constexpr size_t lds_bytes = (2 * 2 * IMG + 2 * IMG + NBLK * 4096 + NBLK * IMG + 8 * PMF_BN * 4 + 16 + 8 * NW + 15) / 16 * 16;
   static constexpr size_t lds_batch(int n_bv) { return PMF_BN * 16 * sizeof(float2) + PMF_PM_BYTES + (size_t)NW * RB * n_bv * 32; }
-  static constexpr int max_bv = PMF_MAXV;
+  static constexpr int max_bv = (int)((160 * 1024 - lds_bytes - PMF_BN * 16 * sizeof(float2) - PMF_PM_BYTES) / (NW * RB * 32)) < PMF_MAXV
+                                    ? (int)((160 * 1024 - lds_bytes - PMF_BN * 16 * sizeof(float2) - PMF_PM_BYTES) / (NW * RB * 32)) : PMF_MAXV;
 };
+// bf16 row image of a Y tile (GEMM2's transposed reads): the layouts of the other split kernels (256-byte rows at Kp = 128,
+// 128-byte rows at Kp = 64), conflict-free for ds_read_b64_tr_b16
+template <int KB>
+__host__ __device__ __forceinline__ int pmf_sb8_y_off(int row, int ch) { return KB == 4 ? pmf_sb4_off(row, ch) : pmf_sb_off<2>(row, ch); }
 struct Sb8SplitArgs {
-  const float *src;       // [n][Kp] f32
+  const float *src;       // [n][Kp] f32 (Kp = 32 KB)
   const float4 *colp;     // .x = sigma (Y) or null (X)
   const float *scale;     // device scalar: power-of-two pre-scale of the f16 images
   int64_t n, nblk;
@@ -286,7 +296,8 @@ struct Sb8SplitArgs {
 struct Sb8ScaleArgs {
   const float *src;
   const float4 *colp;
-  int64_t n;              // rows of src (Kp = 128 floats each)
+  int64_t n;              // rows of src
+  int32_t Kp;             // floats per row
   uint32_t *max_bits;     // scratch word (zeroed by the launcher)
   float *scale_out;       // the device scalar the images and the fused kernel read
 };
@@ -415,9 +426,11 @@ int pmf_launch_fused_sb4_4_bf16(PmfDynLds *cache, hipStream_t stream, const Fuse
 int pmf_launch_fused_sb4_3(PmfDynLds *cache, hipStream_t stream, const FusedArgs &a, int grid, bool batch, bool mixed, bool want_gx, bool want_gy);
 int pmf_launch_fused_sb4_3_bf16(PmfDynLds *cache, hipStream_t stream, const FusedArgs &a, int grid, bool batch, bool mixed, bool want_gx, bool want_gy);
 int pmf_launch_sb4_split(hipStream_t stream, const Sb4SplitArgs &a);
-int pmf_launch_fused_sb8(PmfDynLds *cache, hipStream_t stream, const FusedArgs &a, int grid, bool batch, bool mixed);
-int pmf_launch_fused_sb8_bf16(PmfDynLds *cache, hipStream_t stream, const FusedArgs &a, int grid, bool batch, bool mixed);
-int pmf_launch_sb8_split(hipStream_t stream, const Sb8SplitArgs &a);
+int pmf_launch_fused_sb8_4(PmfDynLds *cache, hipStream_t stream, const FusedArgs &a, int grid, bool batch, bool mixed);
+int pmf_launch_fused_sb8_4_bf16(PmfDynLds *cache, hipStream_t stream, const FusedArgs &a, int grid, bool batch, bool mixed);
+int pmf_launch_fused_sb8_2(PmfDynLds *cache, hipStream_t stream, const FusedArgs &a, int grid, bool batch, bool mixed);
+int pmf_launch_fused_sb8_2_bf16(PmfDynLds *cache, hipStream_t stream, const FusedArgs &a, int grid, bool batch, bool mixed);
+int pmf_launch_sb8_split(hipStream_t stream, const Sb8SplitArgs &a, int KB);
 int pmf_launch_sb8_scale(hipStream_t stream, const Sb8ScaleArgs &a);
 int pmf_launch_sb_split_1(hipStream_t stream, const SbSplitArgs &a);
 int pmf_launch_sb_split_2(hipStream_t stream, const SbSplitArgs &a);

@@ -1560,13 +1560,19 @@ FusedGeom fused_geometry(pmf_ctx *c, bool want_gx, bool want_gy, bool allow_chun
   if (g.sb) g.RBW = 1;
   // 96 < K <= 128, both gradients: the 256-row-panel kernel (pmf_fused_sb8.hip.inc: four waves x two row blocks; PMF_SB8=0
   // keeps pmf_fused_sb4_kernel's 128-row panel).  Batch layers need the panel-local slots of the taller panel.
-  g.sb8 = g.sb && c->KB == 4 && want_gx && want_gy && !(getenv("PMF_SB8") && atoi(getenv("PMF_SB8")) == 0);
+  // (also 32 < K <= 64: four waves x four row blocks, 512-row panel; PMF_SB8=4 restricts it to K > 96)
+  {
+    const char *e8 = getenv("PMF_SB8");
+    const int m8 = e8 ? atoi(e8) : 1;
+    g.sb8 = g.sb && want_gx && want_gy && m8 != 0 && (c->KB == 4 || (c->KB == 2 && m8 != 4));
+  }
+  const int bm8 = c->KB == 4 ? Sb8Cfg<4>::BM : Sb8Cfg<2>::BM;
   if (g.sb8 && c->n_bv > 0) {
     PanelSlots *ps8 = nullptr;
-    if (ensure_panel_slots(c, Sb8Cfg::BM, &ps8) == 0 && ps8 && ps8->ok) g.ps = ps8;
+    if (c->n_bv <= (c->KB == 4 ? Sb8Cfg<4>::max_bv : Sb8Cfg<2>::max_bv) && ensure_panel_slots(c, bm8, &ps8) == 0 && ps8 && ps8->ok) g.ps = ps8;
     else g.sb8 = false;
   }
-  if (g.sb8) g.RBW = Sb8Cfg::RB;
+  if (g.sb8) { g.NW = 4; g.RBW = bm8 / 128; }
   g.BM = 32 * g.NW * g.RBW;
   g.n_rp = (c->M + g.BM - 1) / g.BM;
   g.n_ct_all = (c->N + PMF_BN - 1) / PMF_BN;
@@ -1691,11 +1697,11 @@ int prepare_fused_pass(pmf_ctx *c, const FusedGeom &g, bool want_gx, bool want_g
   }
   PMFCHK(ensure_tile_flags(c));
   if (g.sb) {
-    const size_t xblk = c->KB == 1 ? SbCfg<1>::BLK : (c->KB == 2 ? SbCfg<2>::BLK : Sb4Cfg<4>::XBLK);
-    const size_t yblk = c->KB == 1 ? SbCfg<1>::BLK : (c->KB == 2 ? SbCfg<2>::BLK : std::max<size_t>(Sb4Cfg<4>::YBLK, Sb8Cfg::YBLK));
+    const size_t xblk = c->KB == 1 ? SbCfg<1>::BLK : (c->KB == 2 ? std::max<size_t>(SbCfg<2>::BLK, Sb8Cfg<2>::XBLK) : Sb4Cfg<4>::XBLK);
+    const size_t yblk = c->KB == 1 ? SbCfg<1>::BLK : (c->KB == 2 ? std::max<size_t>(SbCfg<2>::BLK, Sb8Cfg<2>::YBLK) : std::max<size_t>(Sb4Cfg<4>::YBLK, Sb8Cfg<4>::YBLK));
     const size_t xb = (size_t)c->nRB * xblk, yb = (size_t)g.n_ct_all * yblk;
-    // (+ eight zeroed row blocks: pmf_fused_sb8_kernel reads the blocks of a ragged last panel without clamping)
-    if (xb > c->xsb_cap) { dev_free(&c->xsb); c->xsb_cap = 0; PMFCHK(dev_alloc(&c->xsb, xb + 8 * xblk, true)); c->xsb_cap = xb; }
+    // (+ sixteen zeroed row blocks: pmf_fused_sb8_kernel reads the blocks of a ragged last panel without clamping)
+    if (xb > c->xsb_cap) { dev_free(&c->xsb); c->xsb_cap = 0; PMFCHK(dev_alloc(&c->xsb, xb + 16 * xblk, true)); c->xsb_cap = xb; }
     if (yb > c->ysb_cap) { dev_free(&c->ysb); c->ysb_cap = 0; PMFCHK(dev_alloc(&c->ysb, yb, false)); c->ysb_cap = yb; }
     if (g.sb8 && !c->sb8_scale) {
       PMFCHK(dev_alloc(&c->sb8_scale, (size_t)(1 + PMF_MAX_CHUNKS), false));
@@ -1709,10 +1715,10 @@ int prepare_fused_pass(pmf_ctx *c, const FusedGeom &g, bool want_gx, bool want_g
 // chunk of the previous epoch may not have run yet when an earlier chunk is launched, pmf_fit)
 // pmf_fused_sb8_kernel's images: the power-of-two pre-scale of the f16 pair first (a device scalar: no host round trip)
 static int sb8_split(pmf_ctx *c, const float *src, const float4 *colp, int64_t n, int64_t nblk, int slot, int transposed, char *out) {
-  Sb8ScaleArgs sa = {src, colp, n, c->sb8_max + slot, c->sb8_scale + slot};
+  Sb8ScaleArgs sa = {src, colp, n, c->Kp, c->sb8_max + slot, c->sb8_scale + slot};
   PMFCHK(pmf_launch_sb8_scale(c->stream, sa));
   Sb8SplitArgs sp = {src, colp, c->sb8_scale + slot, n, nblk, transposed, out};
-  return pmf_launch_sb8_split(c->stream, sp);
+  return pmf_launch_sb8_split(c->stream, sp, c->KB);
 }
 static int sb_split_x(pmf_ctx *c, bool sb8) {
   if (sb8) return sb8_split(c, c->P[0].p, nullptr, c->M, c->nRB, 0, 1, c->xsb);
@@ -1727,7 +1733,7 @@ static int sb_split_y(pmf_ctx *c, int64_t ct0, int64_t nct, bool sb8, int chunk)
   if (sb8) {
     const int64_t c0 = ct0 * 32;
     return sb8_split(c, c->P[1].p + c0 * c->Kp, c->colp + c0, std::min<int64_t>(c->N - c0, nct * 32), nct, 1 + chunk, 0,
-                     c->ysb + (size_t)ct0 * Sb8Cfg::YBLK);
+                     c->ysb + (size_t)ct0 * (c->KB == 4 ? Sb8Cfg<4>::YBLK : Sb8Cfg<2>::YBLK));
   }
   if (c->KB > 2) {
     const int64_t c0 = ct0 * 32;
@@ -1816,7 +1822,8 @@ int launch_fused_chunk(pmf_ctx *c, const FusedGeom &g, int s, bool want_gx, bool
                    : c->KB == 3 ? (d16 ? pmf_launch_fused_sb4_3_bf16 : pmf_launch_fused_sb4_3)
                                 : (d16 ? pmf_launch_fused_sb4_4_bf16 : pmf_launch_fused_sb4_4);
     c->last_kernel = g.sb8 ? 8 : (c->KB >= 3 ? 4 : (c->KB == 2 && use_sb2 ? 2 : 1));
-    if (g.sb8) rc = (d16 ? pmf_launch_fused_sb8_bf16 : pmf_launch_fused_sb8)(&c->dyn_lds, c->stream, a, grid, batch, c->mixed);
+    if (g.sb8) rc = (c->KB == 4 ? (d16 ? pmf_launch_fused_sb8_4_bf16 : pmf_launch_fused_sb8_4)
+                                : (d16 ? pmf_launch_fused_sb8_2_bf16 : pmf_launch_fused_sb8_2))(&c->dyn_lds, c->stream, a, grid, batch, c->mixed);
     else rc = fn(&c->dyn_lds, c->stream, a, grid, batch, c->mixed, want_gx, want_gy);
     c->sb_launches += 1;
   } else {
