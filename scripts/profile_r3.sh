@@ -24,6 +24,10 @@ if [ "${PMF_PROFILE_SET:-all}" = "config4" ]; then   # both flavours of the conf
   prof config4_shard_full "$ROOT/bench.py" $B --M 125000 --N 100000 --K 128 --precision bf16x3 --store bf16 --full-model
   ls "$OUT"; exit 0
 fi
+if [ "${PMF_PROFILE_SET:-all}" = "headline" ]; then
+  prof headline "$ROOT/bench.py" $B
+  ls "$OUT"; exit 0
+fi
 if [ "${PMF_PROFILE_SET:-all}" = "full_model" ]; then   # the full-model flavours only (added late in round 2)
   prof config4_shard_full "$ROOT/bench.py" $B --M 125000 --N 100000 --K 128 --precision bf16x3 --store bf16 --full-model
   prof config2_full "$ROOT/bench.py" $B --M 20000 --N 10000 --K 32 --full-model
