@@ -58,6 +58,22 @@ set_store!(mode::Symbol) = (STORE[] = mode == :f32 ? 0 : mode == :bf16 ? 1 : err
 #     PathMatFacHIP.comm_init!(model, rank, nranks, id)         # every rank, before fit!
 # From then on mf_fit! all-reduces grad(Y), the loss and the layer gradients inside pmf_fit (DESIGN.md 5); the
 # statistics the host keeps between the GD stages go through comm_allreduce!.
+# HIP devices visible to this process (pmf_device_count).  A launcher that pins one device per rank leaves ONE visible device,
+# which is device 0 whatever the local rank: device_for_rank mirrors bench.py's map.
+function device_count()
+    n = Ref{Cint}(0)
+    chk(ccall((:pmf_device_count, LIB[]), Cint, (Ref{Cint},), n))
+    return Int(n[])
+end
+device_for_rank(local_rank::Integer) = (v = device_count(); v == 1 ? 0 : (local_rank < v ? Int(local_rank) :
+    error("local rank $local_rank has no device: only $v visible")))
+# kernel family of the last fused data pass (pmf_debug_last_kernel): 0 exact f32, 1 / 2 / 4 / 8 = split kernels sb / sb2 / sb4 / sb8
+function last_kernel(model)
+    k = Ref{Cint}(0)
+    chk(ccall((:pmf_debug_last_kernel, LIB[]), Cint, (Ptr{Cvoid}, Ref{Cint}), context!(model), k))
+    return Int(k[])
+end
+
 function comm_unique_id()
     id = zeros(UInt8, 128)
     GC.@preserve id chk(ccall((:pmf_comm_get_unique_id, LIB[]), Cint, (Ptr{UInt8},), id))
