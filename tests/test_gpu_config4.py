@@ -205,3 +205,76 @@ def test_sb8_column_chunks_and_kernel_selection(sctx):
     finally:
         del os.environ["PMF_SB8"]
     assert abs(l4 - l0) <= 2e-6 * abs(l0) and rel_err(g4["X"], g0["X"]) <= 2e-5 and rel_err(g4["Y"], g0["Y"]) <= 2e-5
+
+
+# ---- the 512-row-panel instance of the same kernel (32 < K <= 64: four waves x four row blocks) --------------------------
+K64_CASES = ["ragged_k64_nan", "mixed_k48", "many_panels_k40", "many_panels_two_tiles", "mixed_batch_nan_k64", "batch_many_panels_k40"]
+
+
+@pytest.mark.parametrize("name", K64_CASES)
+def test_k64_both_gradients_run_sb8_and_sb2_agrees(sctx, name):
+    """With both gradients a 32 < K <= 64 pass runs pmf_fused_sb8_kernel<2> (family 8); PMF_SB8=4 keeps that family for
+    K > 96 only and puts the pass back on pmf_fused_sb2_kernel (family 2).  Both against the fp64 oracle on the same problem
+    (the parity cases of tests/test_gpu_split_bf16.py), so the older kernel keeps its both-gradient coverage."""
+    import os
+    from test_gpu_split_bf16 import CASES
+    ctx, n0 = sctx
+    p = make_problem(seed=11, **CASES[name])
+    to_context(p, ctx)
+    m = to_oracle(p)
+    m.m.n_xreg = 0
+    m.m.n_yreg = 0
+    _, gd = m.loss_and_grads(update_X=True, update_Y=True)
+    for env, family in ((None, 8), ("4", 2)):
+        if env is not None:
+            os.environ["PMF_SB8"] = env
+        try:
+            loss, g = grads_of(ctx, p, update_X=True, update_Y=True)
+        finally:
+            os.environ.pop("PMF_SB8", None)
+        assert ctx.last_kernel() == family, (ctx.last_kernel(), family)
+        assert abs(loss - gd["data_loss"]) <= LOSS_RTOL * abs(gd["data_loss"]) + 1e-6, (family, loss, gd["data_loss"])
+        assert rel_err(g["X"], gd["X"]) <= GRAD_TOL and rel_err(g["Y"], gd["Y"]) <= GRAD_TOL, (family, rel_err(g["X"], gd["X"]), rel_err(g["Y"], gd["Y"]))
+    assert ctx.get_precision()[1] == n0 + 2
+
+
+def test_k64_more_batch_views_than_the_tall_panel_holds_fall_back_to_sb2(sctx):
+    """The 512-row panel's LDS has room for five views' panel-local batch slots (Sb8Cfg<2>::max_bv); a model with six
+    batch-layer views runs the 128-row kernel instead, with the same results as the oracle."""
+    ctx, n0 = sctx
+    p = make_problem(seed=61, M=1500, N=360, K=64, n_views=6, batch_views=6, n_batches=4, nan_frac=0.05, col_params=True, scale=0.5)
+    to_context(p, ctx)
+    loss, g = grads_of(ctx, p, update_X=True, update_Y=True)
+    assert ctx.last_kernel() == 2 and ctx.get_precision()[1] == n0 + 1
+    m = to_oracle(p)
+    m.m.n_xreg = 0
+    m.m.n_yreg = 0
+    _, gd = m.loss_and_grads(update_X=True, update_Y=True)
+    assert abs(loss - gd["data_loss"]) <= LOSS_RTOL * abs(gd["data_loss"]) + 1e-6
+    assert rel_err(g["X"], gd["X"]) <= GRAD_TOL and rel_err(g["Y"], gd["Y"]) <= GRAD_TOL
+    p5 = make_problem(seed=61, M=1500, N=360, K=64, n_views=5, batch_views=5, n_batches=4, nan_frac=0.05, col_params=True, scale=0.5)
+    to_context(p5, ctx)
+    grads_of(ctx, p5, update_X=True, update_Y=True)
+    assert ctx.last_kernel() == 8
+
+
+@pytest.mark.parametrize("opt", ["adagrad", "adam"])
+def test_k64_fit_trajectory_through_sb8(sctx, opt):
+    """Ten epochs of the mixed-noise, batch-layer K = 64 problem.  AdaGrad's first step is lr g / (|g| + eps): an entry of gY
+    that is 1e-5 of max|gY| moves by the full lr in the direction of its sign, so the three-term gradient products (4e-6 of
+    max|g|) show up as 5e-3 of max|Y| after ten epochs -- in this kernel and in pmf_fused_sb2_kernel alike (4.8e-3; the exact
+    kernel: 2.5e-5).  Adam's bias-corrected first step has the same property but its eps-floor sits lower: 8e-6."""
+    ctx, n0 = sctx
+    from test_gpu_split_bf16 import CASES
+    p = make_problem(seed=13, random_init=True, **CASES["mixed_batch_nan_k64"])
+    lr = 0.05 if opt == "adagrad" else 0.01
+    to_context(p, ctx)
+    ctx.set_optimizer(opt, lr=lr)
+    r = ctx.fit(update_X=True, update_Y=True, max_epochs=10, abs_tol=0, rel_tol=0)
+    assert ctx.get_precision()[1] == n0 + 10 and ctx.last_kernel() == 8
+    m = to_oracle(p)
+    ro = m.fit(update_X=True, update_Y=True, opt=opt, lr=lr, max_epochs=10, abs_tol=0, rel_tol=0)
+    np.testing.assert_allclose(r["loss"], ro["loss"], rtol=5e-5)
+    X, Y = ctx.get_factors()
+    tol = FIT_TOL if opt == "adam" else 1e-2
+    assert rel_err(X, m.X) <= tol and rel_err(Y, m.Y) <= tol, (rel_err(X, m.X), rel_err(Y, m.Y))
