@@ -1,5 +1,6 @@
 """Randomised parity sweep: HIP path vs the fp64 oracle on random shapes / models (development aid, GPU box).
 python scripts/fuzz_parity.py [n_cases] [seed] [split]
+"sb8": like "split" with both gradients and K in 33..64 / 97..128 (pmf_fused_sb8_kernel's scope; the family is printed).
 "split" selects the opt-in split-bf16 pass (pmf_set_precision), draws K from 1..128, both gradients / grad(X) only / grad(Y) only, and checks that the split kernel was the one launched whenever the
 launch is in its scope (the per-entry gather variant of the batch layers, bmode 2, is not).
 Round 2: views with up to 100 batches in sorted / scrambled / mixed row order, D stored as bf16 (the oracle is fed the
@@ -16,8 +17,10 @@ from problems import make_problem, rel_err, to_context, to_oracle
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 60
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 ctx = pkg.Context(0)
-SPLIT = len(sys.argv) > 3 and sys.argv[3] == "split"
-if SPLIT:
+SPLIT = len(sys.argv) > 3 and sys.argv[3] in ("split", "sb8")
+SB8 = len(sys.argv) > 3 and sys.argv[3] == "sb8"      # "sb8": both gradients, K in 33..64 or 97..128 -- the scope of pmf_fused_sb8_kernel
+import os
+if SPLIT and os.environ.get("PMF_FUZZ_F32") != "1":      # PMF_FUZZ_F32=1: the same cases through the exact kernel
     ctx.set_precision("bf16x3")
 worst = dict(loss=0.0, gx=0.0, gy=0.0, layer=0.0)
 for c in range(n_cases):
@@ -26,6 +29,8 @@ for c in range(n_cases):
     N = int(rng.choice([1, 5, 31, 32, 33, 63, 64, 65, 200, 777, 2500]))
     if SPLIT:
         K = int(rng.integers(1, 65)) if rng.random() < 0.6 else int(rng.integers(65, 129))
+    if SB8:
+        K = int(rng.integers(33, 65)) if rng.random() < 0.5 else int(rng.integers(97, 129))
     if M * N * max(K, 8) > 6e8:   # keep the fp64 oracle in seconds
         N = int(rng.choice([33, 64, 100, 257]))
     nv = int(rng.integers(1, 4))
@@ -51,14 +56,15 @@ for c in range(n_cases):
     to_context(p, ctx)
     if store == "bf16":
         ctx.set_data(p["D"], store="bf16")
-    mode = int(rng.integers(0, 3)) if SPLIT else 0          # 0 both gradients, 1 grad(X) only, 2 grad(Y) only
+    mode = int(rng.integers(0, 3)) if SPLIT and not SB8 else 0          # 0 both gradients, 1 grad(X) only, 2 grad(Y) only
     ux, uy = mode != 2, mode != 1
     o = ctx.make_opts(update_X=ux, update_Y=uy)
     n_split0 = ctx.get_precision()[1]
     ctx.epoch_begin(o)
     loss, _ = ctx.epoch_loss()
     in_scope = ctx.last_path()["bmode"] != 2
-    if SPLIT and in_scope and ctx.get_precision()[1] != n_split0 + 1:
+    fam = ctx.last_kernel()
+    if SPLIT and in_scope and ctx.get_precision()[0] == "bf16x3" and ctx.get_precision()[1] != n_split0 + 1:
         print(f"case {c}: FAIL the split-bf16 kernel was not launched for {kw}")
     gx, gy = (ctx.get_grad("X") if ux else None), (ctx.get_grad("Y") if uy else None)
     m = to_oracle(p)
@@ -80,7 +86,7 @@ for c in range(n_cases):
     bad = el > 2e-5 or ex > 2e-4 or ey > 2e-4 or el2 > 2e-4 or not np.isfinite([el, ex, ey, el2]).all()
     worst = dict(loss=max(worst["loss"], el), gx=max(worst["gx"], ex), gy=max(worst["gy"], ey), layer=max(worst["layer"], el2))
     lp = ctx.last_path()
-    print(f"case {c:3d} {'FAIL' if bad else 'ok  '} mode={mode} M={M} N={N} K={K} views={nv}/{bv} nb={nb}/{order} store={store} bmode={lp['bmode']} lpath={lp['layer_path']} "
+    print(f"case {c:3d} {'FAIL' if bad else 'ok  '} mode={mode} M={M} N={N} K={K} views={nv}/{bv} nb={nb}/{order} store={store} bmode={lp['bmode']} kernel={fam} lpath={lp['layer_path']} "
           f"bern={bern} pois={pois} nan={kw['nan_frac']}: "
           f"loss {el:.1e} gX {ex:.1e} gY {ey:.1e} layers {el2:.1e}", flush=True)
 print("worst:", worst)
