@@ -282,9 +282,9 @@ def main():
             wl = tr["workload"]
             if (wl["M"], wl["N"], wl["K"], wl["n_gpus"]) == (M, N, K, world) and args.store == "f32" and not args.full_model:
                 trk = tr["split_bf16"] if split_main else tr
-            c4 = tr.get("config4_shard")
-            if c4 and split_main and not args.full_model and (c4["workload"]["M"], c4["workload"]["N"], c4["workload"]["K"], c4["workload"]["n_gpus"],
-                                                              c4["workload"]["store"]) == (M, N, K, world, args.store):
+            c4 = tr.get("config4_shard_full" if args.full_model else "config4_shard")
+            if c4 and split_main and (c4["workload"]["M"], c4["workload"]["N"], c4["workload"]["K"], c4["workload"]["n_gpus"],
+                                      c4["workload"]["store"]) == (M, N, K, world, args.store):
                 trk = c4
             if trk is not None:
                 out["roofline"]["traffic"] = trk["hbm_read_bytes_per_launch"] + trk["hbm_write_bytes_per_launch"]

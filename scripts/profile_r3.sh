@@ -1,5 +1,5 @@
 #!/bin/bash
-# Round-3 rocprofv3 evidence (run through gpurun from the repo root):  bash scripts/profile_r2.sh
+# Round-3 rocprofv3 evidence (run through gpurun from the repo root):  bash scripts/profile_r3.sh   (PMF_PROFILE_SET=big | small | config4 | headline | full_model to run a part)
 # For every workload: one --kernel-trace --stats run and three separate PMC runs (SQ, FETCH_SIZE, WRITE_SIZE); raw output under
 # gpurun_out/prof_r3/<name>/, condensed into profiles/r3_<name>_* by scripts/summarize_r3.py.
 set -uo pipefail
@@ -33,8 +33,18 @@ if [ "${PMF_PROFILE_SET:-all}" = "full_model" ]; then   # the full-model flavour
   prof config2_full "$ROOT/bench.py" $B --M 20000 --N 10000 --K 32 --full-model
   ls "$OUT"; exit 0
 fi
-prof headline "$ROOT/bench.py" $B
-prof config4_shard "$ROOT/bench.py" $B --M 125000 --N 100000 --K 128 --precision bf16x3 --store bf16
+if [ "${PMF_PROFILE_SET:-all}" = "big" ]; then   # the three large workloads (the rest: PMF_PROFILE_SET=small)
+  prof headline "$ROOT/bench.py" $B
+  prof config4_shard "$ROOT/bench.py" $B --M 125000 --N 100000 --K 128 --precision bf16x3 --store bf16
+  prof config4_shard_full "$ROOT/bench.py" $B --M 125000 --N 100000 --K 128 --precision bf16x3 --store bf16 --full-model
+  ls "$OUT"; exit 0
+fi
+if [ "${PMF_PROFILE_SET:-all}" != "small" ]; then
+  prof headline "$ROOT/bench.py" $B
+  prof config4_shard "$ROOT/bench.py" $B --M 125000 --N 100000 --K 128 --precision bf16x3 --store bf16
+  prof config4_shard_full "$ROOT/bench.py" $B --M 125000 --N 100000 --K 128 --precision bf16x3 --store bf16 --full-model
+fi
+prof config2_full "$ROOT/bench.py" $B --M 20000 --N 10000 --K 32 --full-model
 prof config1 "$ROOT/bench.py" $B --M 20000 --N 10000 --K 32
 prof general "$ROOT/scripts/kbench_mixed.py" 100000 50000 64 all
 prof layers "$ROOT/scripts/kbench_layers.py" 100000 50000 64
