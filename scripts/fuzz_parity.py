@@ -4,7 +4,11 @@ python scripts/fuzz_parity.py [n_cases] [seed] [split]
 "split" selects the opt-in split-bf16 pass (pmf_set_precision), draws K from 1..128, both gradients / grad(X) only / grad(Y) only, and checks that the split kernel was the one launched whenever the
 launch is in its scope (the per-entry gather variant of the batch layers, bmode 2, is not).
 Round 2: views with up to 100 batches in sorted / scrambled / mixed row order, D stored as bf16 (the oracle is fed the
-rounded matrix), the layer pass with wide batch tables."""
+rounded matrix), the layer pass with wide batch tables.
+PMF_FUZZ_ONLY=c replays case c of a sweep with the layer gradients' errors per parameter.  Known outliers of the 2e-4 layer
+threshold (round 3, 1000 cases): column sums over 70000 rows in ONE batch reach 2.8e-4 of max|gradient| (0.045 absolute on sums
+of 7000 in absolute value: the f32 MFMA's rounding is not unbiased and the bias adds up coherently down a column), and
+gradients that cancel to 1e-3 (M = 31, N = 1) show their 2e-6 absolute error as 2.8e-3."""
 import sys
 from pathlib import Path
 import numpy as np
@@ -44,8 +48,12 @@ for c in range(n_cases):
               bernoulli_frac=bern, poisson_frac=pois, nan_frac=float(rng.choice([0.0, 0.0, 0.05, 0.5])),
               weights=bool(rng.integers(0, 2)), col_params=bool(rng.integers(0, 2)), scale=0.4,
               xreg=rng.choice([None, "l2", "group"]), yreg=rng.choice([None, "fsard", "ard", "group"]), batch_order=order)
+    pseed = int(rng.integers(1 << 30))
+    mode = int(rng.integers(0, 3)) if SPLIT and not SB8 else 0          # 0 both gradients, 1 grad(X) only, 2 grad(Y) only
+    if os.environ.get("PMF_FUZZ_ONLY") and c != int(os.environ["PMF_FUZZ_ONLY"]):   # replay one case of a sweep
+        continue
     try:
-        p = make_problem(seed=int(rng.integers(1 << 30)), **kw)
+        p = make_problem(seed=pseed, **kw)
     except Exception as e:   # a shape the generator itself cannot build (e.g. more batches than rows)
         print(f"case {c}: generator skipped {kw}: {e}")
         continue
@@ -56,7 +64,6 @@ for c in range(n_cases):
     to_context(p, ctx)
     if store == "bf16":
         ctx.set_data(p["D"], store="bf16")
-    mode = int(rng.integers(0, 3)) if SPLIT and not SB8 else 0          # 0 both gradients, 1 grad(X) only, 2 grad(Y) only
     ux, uy = mode != 2, mode != 1
     o = ctx.make_opts(update_X=ux, update_Y=uy)
     n_split0 = ctx.get_precision()[1]
@@ -80,9 +87,15 @@ for c in range(n_cases):
         m2 = to_oracle(p)
         m2.m.has_colreg = 0; m2.m.has_batchreg = 0
         _, g2 = m2.loss_and_grads(update_col_layers=True)
-        el2 = max(rel_err(ctx.get_grad("mu"), g2["mu"]), rel_err(ctx.get_grad("logsigma"), g2["logsigma"]))
+        parts = dict(mu=rel_err(ctx.get_grad("mu"), g2["mu"]), logsigma=rel_err(ctx.get_grad("logsigma"), g2["logsigma"]))
         for v in range(len(p["batch_views"])):
-            el2 = max(el2, rel_err(ctx.get_grad("theta", v), g2["theta"][v]), rel_err(ctx.get_grad("logdelta", v), g2["logdelta"][v]))
+            parts[f"theta{v}"] = rel_err(ctx.get_grad("theta", v), g2["theta"][v])
+            parts[f"logdelta{v}"] = rel_err(ctx.get_grad("logdelta", v), g2["logdelta"][v])
+        el2 = max(parts.values())
+        if os.environ.get("PMF_FUZZ_ONLY"):
+            print("layer gradient errors:", {k: f"{v:.1e}" for k, v in parts.items()})
+            print("max|grad|:", dict(mu=float(np.max(np.abs(g2["mu"]))), logsigma=float(np.max(np.abs(g2["logsigma"])))),
+                  [(float(np.max(np.abs(g2["theta"][v]))), float(np.max(np.abs(g2["logdelta"][v])))) for v in range(len(p["batch_views"]))])
     bad = el > 2e-5 or ex > 2e-4 or ey > 2e-4 or el2 > 2e-4 or not np.isfinite([el, ex, ey, el2]).all()
     worst = dict(loss=max(worst["loss"], el), gx=max(worst["gx"], ex), gy=max(worst["gy"], ey), layer=max(worst["layer"], el2))
     lp = ctx.last_path()
