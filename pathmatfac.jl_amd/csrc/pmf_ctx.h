@@ -44,7 +44,7 @@ struct PanelSlots {
 
 // Cached work split of one column chunk of the fused data pass (see compute_work_split).
 struct WorkSplit {
-  int64_t key[10] = {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1};
+  int64_t key[11] = {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1};
   int grid = 0;
   int64_t serial = 0;
   int64_t *wg_begin = nullptr;     // [grid + 1] device: first work item of each workgroup

@@ -1375,8 +1375,23 @@ __global__ __launch_bounds__(256) void k_gx_reduce(const float *__restrict__ par
 // its 32 columns (measured on MI355X: a Bernoulli tile costs 1.4x a Gaussian one, Poisson 1.3x); with Gaussian-only
 // data this is the even split g*T/G.  Also numbers the pieces (the part of one (segment, row panel) unit inside one
 // workgroup's range) in sequence order: piece p of the chunk owns slot p of the chunk's gX partial slabs.
-static int compute_work_split(pmf_ctx *c, WorkSplit &ws, int grid, int64_t n_rp, int64_t ct0, int64_t n_ct, int64_t tps, int64_t n_cseg) {
-  const int64_t key[10] = {c->M, c->N, c->Kp, grid, n_rp, tps, n_cseg, c->kind_version, ct0, n_ct};
+// Cost of a Bernoulli / Poisson tile in sixteenths of a Gaussian tile's, per kernel family and k-block count.  MEASURED: the
+// weight that minimises the launch time at 100000 x 50000 with 20 % Bernoulli columns (scripts/kbench_mixed.py ... mixed under
+// PMF_W_BERN=w; round 3).  It is not the ratio of the two tiles' times in isolation (1.19-1.58): the workgroups that own the
+// Bernoulli columns do VALU work at the clock the OTHER workgroups' matrix work leaves them.  One weight for all kernels
+// (22, right for the exact kernel at K = 64) cost the split kernels 7-22 % and the exact kernel at K <= 32 12 %.
+static void noise_tile_weights(int KB, bool split, int64_t &w_bern, int64_t &w_pois) {
+  static const int64_t wb_exact[4] = {26, 22, 20, 20}, wb_split[4] = {31, 30, 24, 24};
+  w_bern = (split ? wb_split : wb_exact)[KB - 1];
+  if (getenv("PMF_W_BERN")) w_bern = std::max(16, atoi(getenv("PMF_W_BERN")));
+  w_pois = 16 + ((w_bern - 16) * 5 + 3) / 6;       // (exp only against exp + log + rcp: the exact kernel's 21 against 22)
+  if (getenv("PMF_W_POIS")) w_pois = std::max(16, atoi(getenv("PMF_W_POIS")));
+}
+
+static int compute_work_split(pmf_ctx *c, WorkSplit &ws, int grid, int64_t n_rp, int64_t ct0, int64_t n_ct, int64_t tps, int64_t n_cseg, bool split) {
+  int64_t w_bern, w_pois;
+  noise_tile_weights(c->KB, split, w_bern, w_pois);
+  const int64_t key[11] = {c->M, c->N, c->Kp, grid, n_rp, tps, n_cseg, c->kind_version, ct0, n_ct, c->mixed ? w_bern * 64 + w_pois : 0};
   if (ws.wg_begin && memcmp(key, ws.key, sizeof(key)) == 0) return 0;
   std::vector<int64_t> tw((size_t)n_ct, 16);
   if (c->mixed && (int64_t)c->h_kind.size() == c->N) {
@@ -1384,7 +1399,7 @@ static int compute_work_split(pmf_ctx *c, WorkSplit &ws, int grid, int64_t n_rp,
       int64_t wmax = 16;
       for (int64_t j = (ct0 + ct) * 32; j < std::min<int64_t>(c->N, (ct0 + ct) * 32 + 32); ++j) {
         const int k = c->h_kind[(size_t)j];
-        wmax = std::max<int64_t>(wmax, k == PMF_NOISE_BERNOULLI ? 22 : (k == PMF_NOISE_POISSON ? 21 : 16));
+        wmax = std::max<int64_t>(wmax, k == PMF_NOISE_BERNOULLI ? w_bern : (k == PMF_NOISE_POISSON ? w_pois : 16));
       }
       tw[(size_t)ct] = wmax;
     }
@@ -1646,7 +1661,7 @@ int prepare_fused_pass(pmf_ctx *c, const FusedGeom &g, bool want_gx, bool want_g
   for (int s = 0; s < g.S; ++s) {
     int grid; int64_t tps, n_cseg;
     chunk_segments(c, g, s, grid, tps, n_cseg);
-    PMFCHK(compute_work_split(c, c->splits[(size_t)s], grid, g.n_rp, g.ct0[s], g.nct[s], tps, n_cseg));
+    PMFCHK(compute_work_split(c, c->splits[(size_t)s], grid, g.n_rp, g.ct0[s], g.nct[s], tps, n_cseg, g.sb));
     grid_sum += grid;
   }
   serial_sum = c->split_serial * PMF_MAX_CHUNKS + g.S;   // (split_serial is bumped by every recomputed split)
