@@ -1380,26 +1380,34 @@ __global__ __launch_bounds__(256) void k_gx_reduce(const float *__restrict__ par
 // PMF_W_BERN=w; round 3).  It is not the ratio of the two tiles' times in isolation (1.19-1.58): the workgroups that own the
 // Bernoulli columns do VALU work at the clock the OTHER workgroups' matrix work leaves them.  One weight for all kernels
 // (22, right for the exact kernel at K = 64) cost the split kernels 7-22 % and the exact kernel at K <= 32 12 %.
-static void noise_tile_weights(int KB, bool split, int64_t &w_bern, int64_t &w_pois) {
+// With batch layers EVERY tile pays the table look-ups (w_batch, from the batch-only against the plain launch at the same size),
+// which lowers the Bernoulli tiles' relative weight.
+static void noise_tile_weights(int KB, bool split, bool batch, int64_t &w_gauss, int64_t &w_bern, int64_t &w_pois) {
   static const int64_t wb_exact[4] = {26, 22, 20, 20}, wb_split[4] = {31, 30, 24, 24};
+  static const int64_t we_exact[4] = {6, 6, 5, 4}, we_split[4] = {12, 8, 6, 6};   // (swept on the all-features launch: PMF_W_BATCH)
   w_bern = (split ? wb_split : wb_exact)[KB - 1];
   if (getenv("PMF_W_BERN")) w_bern = std::max(16, atoi(getenv("PMF_W_BERN")));
   w_pois = 16 + ((w_bern - 16) * 5 + 3) / 6;       // (exp only against exp + log + rcp: the exact kernel's 21 against 22)
   if (getenv("PMF_W_POIS")) w_pois = std::max(16, atoi(getenv("PMF_W_POIS")));
+  int64_t w_batch = batch ? (split ? we_split : we_exact)[KB - 1] : 0;
+  if (batch && getenv("PMF_W_BATCH")) w_batch = std::max(0, atoi(getenv("PMF_W_BATCH")));
+  w_gauss = 16 + w_batch;
+  w_bern += w_batch;
+  w_pois += w_batch;
 }
 
 static int compute_work_split(pmf_ctx *c, WorkSplit &ws, int grid, int64_t n_rp, int64_t ct0, int64_t n_ct, int64_t tps, int64_t n_cseg, bool split) {
-  int64_t w_bern, w_pois;
-  noise_tile_weights(c->KB, split, w_bern, w_pois);
-  const int64_t key[11] = {c->M, c->N, c->Kp, grid, n_rp, tps, n_cseg, c->kind_version, ct0, n_ct, c->mixed ? w_bern * 64 + w_pois : 0};
+  int64_t w_gauss, w_bern, w_pois;
+  noise_tile_weights(c->KB, split, c->n_bv > 0, w_gauss, w_bern, w_pois);
+  const int64_t key[11] = {c->M, c->N, c->Kp, grid, n_rp, tps, n_cseg, c->kind_version, ct0, n_ct, c->mixed ? (w_gauss * 64 + w_bern) * 64 + w_pois : 0};
   if (ws.wg_begin && memcmp(key, ws.key, sizeof(key)) == 0) return 0;
-  std::vector<int64_t> tw((size_t)n_ct, 16);
+  std::vector<int64_t> tw((size_t)n_ct, w_gauss);
   if (c->mixed && (int64_t)c->h_kind.size() == c->N) {
     for (int64_t ct = 0; ct < n_ct; ++ct) {
-      int64_t wmax = 16;
+      int64_t wmax = w_gauss;
       for (int64_t j = (ct0 + ct) * 32; j < std::min<int64_t>(c->N, (ct0 + ct) * 32 + 32); ++j) {
         const int k = c->h_kind[(size_t)j];
-        wmax = std::max<int64_t>(wmax, k == PMF_NOISE_BERNOULLI ? w_bern : (k == PMF_NOISE_POISSON ? w_pois : 16));
+        wmax = std::max<int64_t>(wmax, k == PMF_NOISE_BERNOULLI ? w_bern : (k == PMF_NOISE_POISSON ? w_pois : w_gauss));
       }
       tw[(size_t)ct] = wmax;
     }
