@@ -11,7 +11,7 @@ pkg = pmf_import.load()
 M, N, K = (int(x) for x in sys.argv[1:4])
 mode = sys.argv[4] if len(sys.argv) > 4 else "all"   # all | batch | mixed | nan
 rng = np.random.default_rng(3)
-ctx = pkg.Context(0)
+ctx = pkg.Context(0, lib_path=(Path(os.environ["PMF_LIB"]).resolve() if os.environ.get("PMF_LIB") else None))
 ctx.set_data_device(None, M, N)
 ctx.set_factors((rng.standard_normal((K, M)) * 0.3).astype(np.float32), (rng.standard_normal((K, N)) * 0.3).astype(np.float32))
 ctx.set_col_params((rng.standard_normal(N) * 0.1).astype(np.float32), rng.standard_normal(N).astype(np.float32))

@@ -278,3 +278,37 @@ def test_k64_fit_trajectory_through_sb8(sctx, opt):
     X, Y = ctx.get_factors()
     tol = FIT_TOL if opt == "adam" else 1e-2
     assert rel_err(X, m.X) <= tol and rel_err(Y, m.Y) <= tol, (rel_err(X, m.X), rel_err(Y, m.Y))
+
+
+def test_noise_tile_weights_change_the_split_not_the_result(sctx):
+    """The work split weighs Bernoulli / Poisson tiles by measured per-kernel costs (noise_tile_weights, pmf_hip.hip).  Whatever
+    the weights (PMF_W_BERN / PMF_W_BATCH override them), loss and gradients are those of the oracle: a weight only moves the
+    boundaries between workgroups."""
+    import os
+    ctx, n0 = sctx
+    p = make_problem(seed=71, M=9000, N=700, K=64, bernoulli_frac=0.3, poisson_frac=0.2, n_views=3, batch_views=2, n_batches=6,
+                     nan_frac=0.05, weights=True, col_params=True, scale=0.4)
+    m = to_oracle(p)
+    m.m.n_xreg = 0
+    m.m.n_yreg = 0
+    _, gd = m.loss_and_grads(update_X=True, update_Y=True)
+    res = []
+    for wb, we in ((None, None), ("16", "0"), ("48", "20")):
+        for k, v in (("PMF_W_BERN", wb), ("PMF_W_BATCH", we)):
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+        try:
+            to_context(p, ctx)       # (a new model: the cached split is keyed on the weights, this also drops it)
+            loss, g = grads_of(ctx, p, update_X=True, update_Y=True)
+        finally:
+            os.environ.pop("PMF_W_BERN", None)
+            os.environ.pop("PMF_W_BATCH", None)
+        assert ctx.last_kernel() == 8
+        assert abs(loss - gd["data_loss"]) <= LOSS_RTOL * abs(gd["data_loss"])
+        assert rel_err(g["X"], gd["X"]) <= GRAD_TOL and rel_err(g["Y"], gd["Y"]) <= GRAD_TOL
+        res.append((loss, g))
+    for loss, g in res[1:]:
+        assert abs(loss - res[0][0]) <= 1e-6 * abs(res[0][0])
+        assert rel_err(g["X"], res[0][1]["X"]) <= 1e-5 and rel_err(g["Y"], res[0][1]["Y"]) <= 1e-5
