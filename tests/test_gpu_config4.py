@@ -87,10 +87,11 @@ def test_config4_fit_trajectory_matches_oracle(sctx, opt):
     assert rel_err(X, m.X) <= tol and rel_err(Y, m.Y) <= tol, (rel_err(X, m.X), rel_err(Y, m.Y))
 
 
-def test_config4_shard_size_properties(sctx):
-    """One rank's shard of configs[4]: 125000 x 100000, K = 128, D stored bf16 (25 GB), full model."""
+def full_model_size_properties(sctx, M, N, K, store):
+    """Size-independent properties of a full-model pass (20 % Bernoulli columns, column scale / shift, two batch views x 8 row
+    batches, 10 % missing) through pmf_fused_sb8_kernel: bitwise reproducible loss / gX / gY, the Gaussian part of the loss
+    against the independent statistics kernel, Richardson directional derivative."""
     ctx, n0 = sctx
-    M, N, K = 125000, 100000, 128
     rng = np.random.default_rng(9)
     nb, nbat = N // 5, 8
     X0 = (rng.standard_normal((K, M), dtype=np.float32) * 0.2)
@@ -104,7 +105,7 @@ def test_config4_shard_size_properties(sctx):
         views.append(dict(start1=s, stop1=e, batch_of_row=bor,
                           logdelta=(0.25 * rng.standard_normal((nbat, e - s + 1))).astype(np.float32),
                           theta=(0.25 * rng.standard_normal((nbat, e - s + 1))).astype(np.float32)))
-    ctx.set_data_device(None, M, N, store="bf16")
+    ctx.set_data_device(None, M, N, store=store)
     try:
         ctx.set_factors(X0, Y0)
         ctx.set_col_params(logsigma, mu)
@@ -150,8 +151,19 @@ def test_config4_shard_size_properties(sctx):
         Lg = loss_grad(Xs, Ys, want_grad=False)
         assert abs(Lg - L_gauss) <= 5e-5 * L_gauss, (Lg, L_gauss)
     finally:
-        ctx.set_data_device(None, 64, 64)      # release the 25 GB matrix
+        ctx.set_data_device(None, 64, 64)      # release the matrix
         ctx.set_batch_views([])
+
+
+def test_config4_shard_size_properties(sctx):
+    """One rank's shard of configs[4]: 125000 x 100000, K = 128, D stored bf16 (25 GB), full model."""
+    full_model_size_properties(sctx, 125000, 100000, 128, "bf16")
+
+
+def test_headline_size_full_model_properties_k64(sctx):
+    """The headline matrix (200000 x 50000, K = 64, f32) with the full model: the 512-row-panel instance of the kernel with its
+    batch-layer variant (table planes, five-view limit, late X^T mid loads) at a size with many pieces per workgroup."""
+    full_model_size_properties(sctx, 200000, 50000, 64, "f32")
 
 
 # ---- pmf_fused_sb8_kernel specifics (csrc/pmf_fused_sb8.hip.inc) --------------------------------------------------------
