@@ -1623,8 +1623,12 @@ FusedGeom fused_geometry(pmf_ctx *c, bool want_gx, bool want_gy, bool allow_chun
       const double t_pass = 6.0 * (double)Mref * (double)c->N * (double)c->Kp / (c->precision == PMF_PREC_BF16X3 ? 200e12 : 115e12);
       S = 2;
       while (S < 4 && 30e-6 + bytes / S / algbw > t_pass * (S - 1) / S) ++S;
-      // a chunk should give every workgroup a few dozen tiles at least (each launch pays its prologue and its tail)
-      const int64_t n_rp_ref = (Mref + g.BM - 1) / g.BM;
+      // a chunk should give every workgroup a few dozen tiles at least (each launch pays its prologue and its tail).  Counted
+      // in REFERENCE panels of 256 rows, the unit the threshold was calibrated in -- not g.BM: the panel height belongs to the
+      // kernel family THIS rank runs (512 rows for pmf_fused_sb8_kernel at K <= 64, 128 where a rank's batch layout sends it to
+      // pmf_fused_sb2_kernel), and two ranks that disagreed on it chose different S, i.e. different collectives.
+      constexpr int64_t REF_PANEL = 256;
+      const int64_t n_rp_ref = (Mref + REF_PANEL - 1) / REF_PANEL;
       const int64_t min_tiles = 32ll * std::max(1, c->n_cu - c->comm.reserve_cus);
       while (S > 1 && (n_rp_ref * g.n_ct_all) / S < min_tiles) --S;
     }

@@ -237,14 +237,17 @@ AUTO_N, AUTO_K = 5120, 64                 # 160 column tiles
 AUTO_ROWS = (102 * 256, 104 * 256 + 5)    # 102 and 105 row panels; mean 26370 rows = 104 panels: 104 * 160 / 2 >= 32 * 256 -> S = 2
 
 
-def _worker_auto(rank, world, port, outdir):
+def _worker_auto(rank, world, port, outdir, precision="f32", sb8_off_on_rank=-1):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    if rank == sb8_off_on_rank:      # this rank alone keeps 32 < K <= 64 on pmf_fused_sb2_kernel (128-row panels, not 512)
+        os.environ["PMF_SB8"] = "4"
     import torch
     import torch.distributed as dist
     import pmf_import
     pkg = pmf_import.load()
     dist.init_process_group("gloo", rank=rank, world_size=world)
     ctx = pkg.Context(0)
+    ctx.set_precision(precision)
 
     def allreduce(arr):
         dist.all_reduce(torch.from_numpy(arr))
@@ -271,7 +274,8 @@ def _worker_auto(rank, world, port, outdir):
     h = ctx.fit(update_X=True, update_Y=True, max_epochs=4, abs_tol=0, rel_tol=0)
     info = ctx.comm_info()
     _, Y = ctx.get_factors()
-    np.savez(Path(outdir) / f"auto{rank}.npz", loss=h["loss"], n_chunks=info["n_chunks"], n_coll=info["n_collectives"], Y=Y)
+    np.savez(Path(outdir) / f"auto{rank}.npz", loss=h["loss"], n_chunks=info["n_chunks"], n_coll=info["n_collectives"], Y=Y,
+             family=ctx.last_kernel())
     ctx.comm_destroy()
     ctx.close()
     dist.destroy_process_group()
@@ -313,3 +317,31 @@ def test_one_rank_rccl_with_the_per_communicator_cta_cap(pkg, ctx, monkeypatch):
     np.testing.assert_array_equal(r1["loss"], r0["loss"])
     np.testing.assert_array_equal(X1, X0)
     np.testing.assert_array_equal(Y1, Y0)
+
+
+def test_two_ranks_on_different_kernel_families_choose_the_same_automatic_chunks(tmp_path):
+    """The automatic chunk count must not depend on the kernel family a rank happens to run: in split mode at K = 64 rank 0
+    runs pmf_fused_sb8_kernel (512-row panels), rank 1 is kept on pmf_fused_sb2_kernel (128-row panels).  Counted in each
+    rank's own panels (a first version) the threshold gave S = 1 on rank 0 (52 panels x 160 tiles / 2 < 32 x 256) and S = 2 on
+    rank 1 (207 panels): different collectives.  Counted in reference panels both choose S = 2."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    code = ("import sys; sys.path[:0] = [%r, %r]; import test_gpu_comm as t; "
+            "t._worker_auto(int(sys.argv[1]), 2, int(sys.argv[2]), sys.argv[3], 'bf16x3', 1)") % (str(ROOT), str(ROOT / "tests"))
+    procs = [subprocess.Popen([sys.executable, "-c", code, str(r), str(port), str(tmp_path)]) for r in range(2)]
+    try:
+        for pr in procs:
+            assert pr.wait(timeout=240) == 0
+    finally:
+        for pr in procs:      # (a rank left waiting in a collective must not outlive the test)
+            if pr.poll() is None:
+                pr.kill()
+    a, b = (np.load(tmp_path / f"auto{k}.npz") for k in range(2))
+    assert (int(a["family"]), int(b["family"])) == (8, 2), (int(a["family"]), int(b["family"]))
+    assert int(a["n_chunks"]) == int(b["n_chunks"]) == 2, (int(a["n_chunks"]), int(b["n_chunks"]))
+    assert int(a["n_coll"]) == int(b["n_coll"])
+    np.testing.assert_array_equal(a["loss"], b["loss"])
+    np.testing.assert_array_equal(a["Y"], b["Y"])
+    assert a["loss"][-1] < a["loss"][0]
+
